@@ -1,0 +1,110 @@
+/*
+ * wkv6_amd.h -- C ABI of librwkv6_amd.so: the MI355X (gfx950) implementation of the RWKV-6 WKV
+ * operator family of yynil/RWKV_LM_EXT.
+ *
+ * Every entry point takes plain device pointers and sizes (no torch types) plus the HIP stream to
+ * launch on, and returns 0 on success or a negative WKV6_E* / positive hipError_t code; nothing is
+ * launched when arguments are rejected.  All tensors are contiguous, layouts as in the reference:
+ *   r,k,v,w,y,gy,gr,gk,gv,gw : [B,T,C]     u : [H,N]     gu : [B,C] (per-batch partials)
+ *   N = C/H = 64 (the reference build's -D_N_, src/model.py:189)
+ * bf16 buffers are passed as void* (raw bfloat16 bits).
+ *
+ * The first four pairs are drop-in replacements for the `cuda_forward` / `cuda_backward` C symbols
+ * that the reference's torch-extension shims call; each has the reference's parameter list with
+ * one trailing `stream`.  The *_ex entry points expose what the reference cannot express (bf16 raw
+ * decay without the fp32 `ew` pass, fp32 I/O for numerics tests, separate in/out state, caller-owned
+ * workspace, per-row lengths).  INTEGRATION.md shows the binding a maintainer would add.
+ */
+#ifndef WKV6_AMD_H
+#define WKV6_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    WKV6_OK = 0,
+    WKV6_EINVAL = -1,      /* bad shape: C != H*64, B/T/C/H < 1 (reference: assert(H*_N_ == C), cuda/wkv6_cuda.cu:231) */
+    WKV6_ENULL = -2,       /* a required pointer is NULL */
+    WKV6_EWORKSPACE = -3,  /* workspace too small / allocation failed */
+    WKV6_EUNSUPPORTED = -4
+};
+
+/* ---- wkv6: replaces cuda_forward / cuda_backward of cuda/wkv6_op.cpp:5-6 (cuda/wkv6_cuda.cu:229-242).
+ * `w` is the fp32 tensor ew = -exp(w_raw) that src/model.py:210 builds. */
+int wkv6_cuda_forward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                      const float* w, const void* u, void* y, void* stream);
+int wkv6_cuda_backward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                       const float* w, const void* u, const void* gy, void* gr, void* gk, void* gv,
+                       void* gw, void* gu, void* stream);
+
+/* ---- wkv6_bi: replaces cuda_forward / cuda_backward of cuda/wkv6_bi_op.cpp:5-6
+ * (cuda/wkv6_bi_cuda.cu:363-377).  mask: int32 [B,T]; both scans cover tokens 0..L_b where L_b is
+ * the first t with mask[b][t]==0 (T-1 if the row has no zero); y and the gradients are 0 for
+ * t > L_b; the backward is the exact adjoint of the forward (deviations Q1-Q3). */
+int wkv6bi_cuda_forward(int B, int T, int C, int H, const int* mask, const void* r, const void* k,
+                        const void* v, const float* w, const void* u, void* y, void* stream);
+int wkv6bi_cuda_backward(int B, int T, int C, int H, const int* mask, const void* r, const void* k,
+                         const void* v, const float* w, const void* u, const void* gy, void* gr,
+                         void* gk, void* gv, void* gw, void* gu, void* stream);
+
+/* ---- wkv6state: replaces cuda/wkv6state_op.cpp:5-6.  `w` is the RAW bf16 decay parameter
+ * (cuda/wkv6state_cuda.cu:30), s: bf16 [H,N,N] (value-major: s[h][j][i]), gs: bf16 [B,H,N,N]. */
+int wkv6state_cuda_forward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                           const void* w, const void* u, const void* s, void* y, void* stream);
+int wkv6state_cuda_backward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                            const void* w, const void* u, const void* s, const void* gy, void* gr,
+                            void* gk, void* gv, void* gw, void* gu, void* gs, void* stream);
+
+/* ---- wkv6infctx: replaces cuda/wkv6infctx_op.cpp:5-6.  s: bf16 [B,H,N,N]; the forward overwrites
+ * it with the final state (cuda/wkv6infctx_cuda.cu:65-67).  The backward must be given the INITIAL
+ * state (the reference hands it the overwritten one; the python wrapper keeps a copy). */
+int wkv6infctx_cuda_forward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                            const void* w, const void* u, void* s, void* y, void* stream);
+int wkv6infctx_cuda_backward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                             const void* w, const void* u, const void* s, const void* gy, void* gr,
+                             void* gk, void* gv, void* gw, void* gu, void* gs, void* stream);
+
+/* ---- extended entry points -------------------------------------------------------------------------
+ * flags (OR together): */
+enum {
+    WKV6_W_EW_F32 = 0,      /* w is fp32 ew = -exp(w_raw)                       (default) */
+    WKV6_W_RAW = 1,         /* w is the raw decay in the I/O type               */
+    WKV6_IO_F32 = 2,        /* every bf16 tensor is fp32 instead (numerics tests) */
+    WKV6_S0_PER_BATCH = 4,  /* s0 is [B,H,N,N] (infctx) instead of [H,N,N] (state) */
+    WKV6_ALGO_SCAN = 16     /* force the exact token-serial kernels            */
+};
+/* Bytes of scratch the backward needs (the forward needs none). */
+size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H);
+
+/* s0 may be NULL (zero initial state); s_out may be NULL; s_out may alias s0. */
+int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                    const void* w, const void* u, const void* s0, void* s_out, void* y,
+                    unsigned flags, void* stream);
+/* gu, gs may be NULL (skipped).  workspace: wkv6_backward_workspace_bytes() bytes, or NULL to use a
+ * library-owned grow-only buffer (not safe for concurrent use from several streams). */
+int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                     const void* w, const void* u, const void* s0, const void* gy, void* gr,
+                     void* gk, void* gv, void* gw, void* gu, void* gs, void* workspace,
+                     size_t workspace_bytes, unsigned flags, void* stream);
+/* lens: int32 [B] device array, number of leading tokens both scans cover (NULL: derive from mask). */
+int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
+                      const void* k, const void* v, const void* w, const void* u, void* y,
+                      void* workspace, size_t workspace_bytes, unsigned flags, void* stream);
+int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
+                       const void* k, const void* v, const void* w, const void* u, const void* gy,
+                       void* gr, void* gk, void* gv, void* gw, void* gu, void* workspace,
+                       size_t workspace_bytes, unsigned flags, void* stream);
+size_t wkv6bi_workspace_bytes(int B, int T, int C, int H);
+
+/* Runs the cross-lane primitive self-test on the current device; returns 0 when it passes. */
+int wkv6_selftest(void* stream);
+/* "major.minor" of the library. */
+const char* wkv6_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WKV6_AMD_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of librwkv6_amd.so (the C ABI declared in include/wkv6_amd.h).
+
+There is deliberately no CPU fallback: if the HIP library cannot be built or loaded, importing the
+operator fails loudly.
+"""
+import ctypes
+import os
+import threading
+
+from . import _build
+
+_VP = ctypes.c_void_p
+_I = ctypes.c_int
+_SZ = ctypes.c_size_t
+_U = ctypes.c_uint
+
+# name -> (restype, argtypes); must list every symbol of include/wkv6_amd.h
+SIGNATURES = {
+    "wkv6_cuda_forward": (_I, [_I] * 4 + [_VP] * 7),
+    "wkv6_cuda_backward": (_I, [_I] * 4 + [_VP] * 12),
+    "wkv6bi_cuda_forward": (_I, [_I] * 4 + [_VP] * 8),
+    "wkv6bi_cuda_backward": (_I, [_I] * 4 + [_VP] * 13),
+    "wkv6state_cuda_forward": (_I, [_I] * 4 + [_VP] * 8),
+    "wkv6state_cuda_backward": (_I, [_I] * 4 + [_VP] * 14),
+    "wkv6infctx_cuda_forward": (_I, [_I] * 4 + [_VP] * 8),
+    "wkv6infctx_cuda_backward": (_I, [_I] * 4 + [_VP] * 14),
+    "wkv6_backward_workspace_bytes": (_SZ, [_I] * 4),
+    "wkv6bi_workspace_bytes": (_SZ, [_I] * 4),
+    "wkv6_forward_ex": (_I, [_I] * 4 + [_VP] * 8 + [_U, _VP]),
+    "wkv6_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
+    "wkv6bi_forward_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ, _U, _VP]),
+    "wkv6bi_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
+    "wkv6_selftest": (_I, [_VP]),
+    "wkv6_amd_version": (ctypes.c_char_p, []),
+}
+
+# flags of include/wkv6_amd.h
+W_EW_F32, W_RAW, IO_F32, S0_PER_BATCH, ALGO_SCAN = 0, 1, 2, 4, 16
+
+ERRORS = {-1: "WKV6_EINVAL (shape: need C == H*64 and B,T,C,H >= 1)", -2: "WKV6_ENULL (null pointer)",
+          -3: "WKV6_EWORKSPACE (workspace too small / allocation failed)", -4: "WKV6_EUNSUPPORTED"}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (building first if the sources are newer) and type the library."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            path = _build.LIB_PATH
+            if os.environ.get("RWKV_AMD_NO_BUILD", "0") != "1":
+                path = _build.build()
+            if not os.path.exists(path):
+                raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+            lib = ctypes.CDLL(path)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = ERRORS.get(rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")
+        raise RuntimeError(f"{what} failed: {msg}")

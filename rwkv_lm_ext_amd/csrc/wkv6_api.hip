@@ -1,0 +1,261 @@
+// extern "C" entry points of librwkv6_amd.so (declared in include/wkv6_amd.h).
+#include "../../include/wkv6_amd.h"
+#include "wkv6_scan.h"
+
+#include <mutex>
+
+using namespace wkv6;
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+
+int check_shape(int B, int T, int C, int H)
+{
+    if (B < 1 || T < 1 || C < 1 || H < 1) return WKV6_EINVAL;
+    if ((long)H * HEAD != (long)C) return WKV6_EINVAL;      // reference: assert(H*_N_ == C)
+    return WKV6_OK;
+}
+
+// Library-owned scratch for the reference-signature entry points (which have no workspace
+// argument).  Grow-only, one per device, serialised by a mutex; callers that use several streams
+// concurrently must pass their own workspace through the *_ex entry points.
+struct Scratch {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+Scratch g_scratch[16];
+std::mutex g_scratch_mu;
+
+void* internal_scratch(size_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    Scratch& s = g_scratch[dev];
+    if (s.bytes < bytes) {
+        if (s.ptr) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(s.ptr);
+            s.ptr = nullptr;
+            s.bytes = 0;
+        }
+        if (hipMalloc(&s.ptr, bytes) != hipSuccess) return nullptr;
+        s.bytes = bytes;
+    }
+    return s.ptr;
+}
+
+// lens[b] = 1 + index of the first zero of mask[b][:], or T when the row has no zero
+// (cuda/wkv6_bi_cuda.cu:21-69 breaks AFTER processing the first masked token).
+__global__ void mask_to_lens_kernel(const int* __restrict__ mask, int* __restrict__ lens, int T)
+{
+    const int b = blockIdx.x;
+    int first = T;                                           // "no zero" sentinel
+    for (int t = threadIdx.x; t < T; t += blockDim.x)
+        if (mask[(long)b * T + t] == 0) { first = t; break; }
+    __shared__ int red[256];
+    red[threadIdx.x] = first;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = min(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) lens[b] = min(red[0] + 1, T);
+}
+
+int to_rc(hipError_t e) { return e == hipSuccess ? WKV6_OK : (int)e; }
+
+ScanArgs base_args(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                   const void* w, const void* u, unsigned flags)
+{
+    ScanArgs a = {};
+    a.B = B; a.T = T; a.C = C; a.H = H;
+    a.r = r; a.k = k; a.v = v; a.w = w; a.u = u;
+    a.wkind = (flags & WKV6_W_RAW) ? 1 : 0;
+    a.use_u = 1;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* wkv6_amd_version(void) { return "0.1"; }
+
+size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H)
+{
+    (void)H;
+    return align_up((size_t)B * T * C * sizeof(float));
+}
+size_t wkv6bi_workspace_bytes(int B, int T, int C, int H)
+{
+    return align_up((size_t)B * sizeof(int)) + wkv6_backward_workspace_bytes(B, T, C, H);
+}
+
+int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                    const void* w, const void* u, const void* s0, void* s_out, void* y,
+                    unsigned flags, void* stream)
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!r || !k || !v || !w || !u || !y) return WKV6_ENULL;
+    ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
+    a.s0 = s0;
+    a.s0_bstride = (flags & WKV6_S0_PER_BATCH) ? (long)H * HEAD * HEAD : 0;
+    a.s_out = s_out;
+    a.y = y;
+    return to_rc(launch_scan_fwd(a, flags & WKV6_IO_F32, (hipStream_t)stream));
+}
+
+int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                     const void* w, const void* u, const void* s0, const void* gy, void* gr,
+                     void* gk, void* gv, void* gw, void* gu, void* gs, void* workspace,
+                     size_t workspace_bytes, unsigned flags, void* stream)
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw) return WKV6_ENULL;
+    const size_t need = wkv6_backward_workspace_bytes(B, T, C, H);
+    if (!workspace) {
+        workspace = internal_scratch(need);
+        if (!workspace) return WKV6_EWORKSPACE;
+    } else if (workspace_bytes < need) {
+        return WKV6_EWORKSPACE;
+    }
+    ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
+    a.s0 = s0;
+    a.s0_bstride = (flags & WKV6_S0_PER_BATCH) ? (long)H * HEAD * HEAD : 0;
+    a.gy = gy; a.gr = gr; a.gk = gk; a.gv = gv; a.gw = gw; a.gu = gu; a.gs = gs;
+    a.aux = reinterpret_cast<float*>(workspace);
+    return to_rc(launch_scan_bwd(a, flags & WKV6_IO_F32, (hipStream_t)stream));
+}
+
+int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
+                      const void* k, const void* v, const void* w, const void* u, void* y,
+                      void* workspace, size_t workspace_bytes, unsigned flags, void* stream)
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!r || !k || !v || !w || !u || !y || (!mask && !lens)) return WKV6_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (!lens) {
+        const size_t need = align_up((size_t)B * sizeof(int));
+        if (!workspace) {
+            workspace = internal_scratch(wkv6bi_workspace_bytes(B, T, C, H));
+            if (!workspace) return WKV6_EWORKSPACE;
+        } else if (workspace_bytes < need) {
+            return WKV6_EWORKSPACE;
+        }
+        int* l = reinterpret_cast<int*>(workspace);
+        hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, l, T);
+        lens = l;
+    }
+    ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
+    a.y = y;
+    a.lens = lens;
+    a.zero_tail = 1;                          // y[t > L_b] = 0 (the reference leaves it uninitialised, Q2)
+    if (hipError_t e = launch_scan_fwd(a, flags & WKV6_IO_F32, st)) return (int)e;
+    a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0;   // cuda/wkv6_bi_cuda.cu:71-111
+    return to_rc(launch_scan_fwd(a, flags & WKV6_IO_F32, st));
+}
+
+int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
+                       const void* k, const void* v, const void* w, const void* u, const void* gy,
+                       void* gr, void* gk, void* gv, void* gw, void* gu, void* workspace,
+                       size_t workspace_bytes, unsigned flags, void* stream)
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw || (!mask && !lens)) return WKV6_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = wkv6bi_workspace_bytes(B, T, C, H);
+    if (!workspace) {
+        workspace = internal_scratch(need);
+        if (!workspace) return WKV6_EWORKSPACE;
+    } else if (workspace_bytes < need) {
+        return WKV6_EWORKSPACE;
+    }
+    int* l = reinterpret_cast<int*>(workspace);
+    float* aux = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * sizeof(int)));
+    if (!lens) {
+        hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, l, T);
+        lens = l;
+    }
+    ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
+    a.gy = gy; a.gr = gr; a.gk = gk; a.gv = gv; a.gw = gw; a.gu = gu;
+    a.aux = aux;
+    a.lens = lens;
+    a.zero_tail = 1;
+    if (hipError_t e = launch_scan_bwd(a, flags & WKV6_IO_F32, st)) return (int)e;   // adjoint of the forward scan
+    a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0; a.gu = nullptr;   // adjoint of the reverse scan
+    return to_rc(launch_scan_bwd(a, flags & WKV6_IO_F32, st));
+}
+
+// ---- reference-signature entry points ------------------------------------------------------------
+int wkv6_cuda_forward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                      const float* w, const void* u, void* y, void* stream)
+{
+    return wkv6_forward_ex(B, T, C, H, r, k, v, w, u, nullptr, nullptr, y, WKV6_W_EW_F32, stream);
+}
+int wkv6_cuda_backward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                       const float* w, const void* u, const void* gy, void* gr, void* gk, void* gv,
+                       void* gw, void* gu, void* stream)
+{
+    return wkv6_backward_ex(B, T, C, H, r, k, v, w, u, nullptr, gy, gr, gk, gv, gw, gu, nullptr,
+                            nullptr, 0, WKV6_W_EW_F32, stream);
+}
+int wkv6bi_cuda_forward(int B, int T, int C, int H, const int* mask, const void* r, const void* k,
+                        const void* v, const float* w, const void* u, void* y, void* stream)
+{
+    return wkv6bi_forward_ex(B, T, C, H, mask, nullptr, r, k, v, w, u, y, nullptr, 0, WKV6_W_EW_F32, stream);
+}
+int wkv6bi_cuda_backward(int B, int T, int C, int H, const int* mask, const void* r, const void* k,
+                         const void* v, const float* w, const void* u, const void* gy, void* gr,
+                         void* gk, void* gv, void* gw, void* gu, void* stream)
+{
+    return wkv6bi_backward_ex(B, T, C, H, mask, nullptr, r, k, v, w, u, gy, gr, gk, gv, gw, gu,
+                              nullptr, 0, WKV6_W_EW_F32, stream);
+}
+int wkv6state_cuda_forward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                           const void* w, const void* u, const void* s, void* y, void* stream)
+{
+    if (!s) return WKV6_ENULL;
+    return wkv6_forward_ex(B, T, C, H, r, k, v, w, u, s, nullptr, y, WKV6_W_RAW, stream);
+}
+int wkv6state_cuda_backward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                            const void* w, const void* u, const void* s, const void* gy, void* gr,
+                            void* gk, void* gv, void* gw, void* gu, void* gs, void* stream)
+{
+    if (!s) return WKV6_ENULL;
+    return wkv6_backward_ex(B, T, C, H, r, k, v, w, u, s, gy, gr, gk, gv, gw, gu, gs, nullptr, 0,
+                            WKV6_W_RAW, stream);
+}
+int wkv6infctx_cuda_forward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                            const void* w, const void* u, void* s, void* y, void* stream)
+{
+    if (!s) return WKV6_ENULL;
+    return wkv6_forward_ex(B, T, C, H, r, k, v, w, u, s, s, y, WKV6_W_RAW | WKV6_S0_PER_BATCH, stream);
+}
+int wkv6infctx_cuda_backward(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                             const void* w, const void* u, const void* s, const void* gy, void* gr,
+                             void* gk, void* gv, void* gw, void* gu, void* gs, void* stream)
+{
+    if (!s) return WKV6_ENULL;
+    return wkv6_backward_ex(B, T, C, H, r, k, v, w, u, s, gy, gr, gk, gv, gw, gu, gs, nullptr, 0,
+                            WKV6_W_RAW | WKV6_S0_PER_BATCH, stream);
+}
+
+int wkv6_selftest(void* stream)
+{
+    int* d = nullptr;
+    if (hipMalloc(&d, sizeof(int)) != hipSuccess) return WKV6_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int host = -1;
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(int), st);
+    if (e == hipSuccess) e = launch_selftest(d, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, d, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) return (int)e;
+    return host;
+}
+
+}  // extern "C"

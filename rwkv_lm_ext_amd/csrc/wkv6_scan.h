@@ -1,0 +1,49 @@
+// Exact-fp32 token-serial WKV6 kernels for gfx950 ("scan" path).
+//
+// These kernels evaluate the recurrence of cuda/wkv6_cuda.cu:6-227 literally (fp32 state, one
+// token after another), re-laid-out for CDNA4:
+//   * one 512-thread workgroup (8 wave64) per (batch, head); the 64x64 state is tiled over the
+//     waves, every lane owns a small i x j sub-block in registers;
+//   * r/k/v/w(/gy) rows are staged 16 tokens at a time through a double-buffered LDS image
+//     (coalesced 128-B row segments from HBM), decays exp(-exp(w)) are formed once per element
+//     while staging;
+//   * the per-token reductions use DPP row operations and v_permlane{16,32}_swap, not LDS;
+//   * backward = two sweeps instead of the reference's five (kernel_backward_111 has three scans,
+//     kernel_backward_222 two): sweep S (forward in scan order) recomputes the state and emits gr
+//     and a_t = r_t (.) sum_j gy_t[j] S_t[.][j]; sweep G (reverse) carries G, emits gk, gv and
+//     b_t = k_t (.) sum_j G_t[.][j] v_t[j] and forms gw from the suffix-sum identity
+//     gew_t = sum_{s>t} a_s - sum_{s>=t} b_s   (fla/ops/rwkv6/recurrent_fuse.py:394-396),
+//     which removes the reference's per-thread float[T] scratch array and its T <= _T_ limit.
+//
+// They are the reference-exact path (any T >= 1, any decay magnitude, optional initial / final
+// state, either time direction, per-row lengths).
+#pragma once
+#include "wkv6_common.h"
+
+namespace wkv6 {
+
+struct ScanArgs {
+    int B, T, C, H;
+    const void *r, *k, *v, *w, *u;   // w: float ew = -exp(w) when wkind == 0, else raw w in the I/O type
+    int wkind;
+    const void* s0;                   // initial state [.., H, N(j), N(i)] in the I/O type, or null (zero)
+    long s0_bstride;                  // elements between batch entries of s0 (0: shared over the batch)
+    void* s_out;                      // final state [B,H,N,N] in the I/O type, or null   (forward only)
+    void* y;                          // forward output
+    const void* gy;                   // backward input
+    void *gr, *gk, *gv, *gw;          // backward outputs, I/O type
+    void* gu;                         // [B,C] per-batch partials, I/O type (null: skip)
+    void* gs;                         // [B,H,N,N] per-batch dL/dS0, I/O type (null: skip)
+    float* aux;                       // [B,T,C] fp32 scratch carrying a_t from sweep S to sweep G
+    const int* lens;                  // per-batch number of tokens to scan (null: T)
+    int reverse;                      // 1: scan tokens lens-1 .. 0
+    int use_u;                        // 0: bonus u treated as 0 (reverse half of wkv6_bi)
+    int accumulate;                   // 1: add into y / gr,gk,gv,gw instead of overwriting
+    int zero_tail;                    // 1: write zeros for tokens >= lens[b]
+};
+
+hipError_t launch_scan_fwd(const ScanArgs& a, bool io_f32, hipStream_t st);
+hipError_t launch_scan_bwd(const ScanArgs& a, bool io_f32, hipStream_t st);
+hipError_t launch_selftest(int* result, hipStream_t st);
+
+}  // namespace wkv6

@@ -1,0 +1,159 @@
+"""Autograd layer: WKV_6 / WKV_6STATE / WKV_6_BI and the RUN_CUDA_RWKV6* helpers of the reference.
+
+Mirrors, argument for argument:
+  WKV_6.apply(B, T, C, H, r, k, v, w, u) -> y                    src/model.py:191-233  (dup src/model_bi.py:49-94)
+  RUN_CUDA_RWKV6(B, T, C, H, r, k, v, w, u)                       src/model.py:235-236
+  WKV_6STATE.apply(B, T, C, H, r, k, v, w, u, s) -> y             src/model.py:137-182 ('states': s [H,N,N])
+                                                                  src/model.py:83-128  ('infctx': s [B,H,N,N])
+  RUN_CUDA_RWKV6_STATE(B, T, C, H, r, k, v, w, u, s)              src/model.py:184-185 (states -> y)
+                                                                  src/model.py:130-132 (infctx -> (y, s))
+  WKV_6_BI.apply(B, T, C, H, mask, r, k, v, w, u) -> y            cuda/wkv6_bi.py:13-60
+
+Same dtype/contiguity asserts and the same gradient tuples.  Differences, all deliberate:
+  * the raw bf16 decay `w` goes straight to the kernel (no fp32 `ew = -exp(w.float())` pass, no fp32
+    tensor kept alive for backward -- src/model.py:210-211);
+  * gu / gs are reduced over the batch in fp32 and rounded once (the reference sums bf16 partials
+    in bf16, src/model.py:232);
+  * infctx keeps the INITIAL state for backward (the reference saves the tensor the kernel then
+    overwrites); the caller's `s` is still updated in place and returned;
+  * WKV_6_BI's backward is the adjoint of its forward.
+"""
+import os
+
+import torch
+
+from . import wkv6_op
+
+HEAD_SIZE = int(os.environ.get("RWKV_HEAD_SIZE_A", "64"))
+
+
+def _assert_inputs(C, H, *tensors):
+    for t in tensors:
+        assert t.dtype == torch.bfloat16
+        assert t.is_contiguous()
+    assert HEAD_SIZE == C // H
+
+
+def _sum_bf16(partials, shape):
+    return partials.float().sum(0).to(torch.bfloat16).view(shape)
+
+
+class WKV_6(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, B, T, C, H, r, k, v, w, u):
+        with torch.no_grad():
+            _assert_inputs(C, H, r, k, v, w, u)
+            ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
+            ctx.save_for_backward(r, k, v, w, u)
+            return wkv6_op.forward_ex(r, k, v, w, u, H)
+
+    @staticmethod
+    def backward(ctx, gy):
+        with torch.no_grad():
+            assert gy.dtype == torch.bfloat16
+            gy = gy.contiguous()
+            r, k, v, w, u = ctx.saved_tensors
+            gr, gk, gv, gw, gu, _ = wkv6_op.backward_ex(r, k, v, w, u, gy, ctx.H)
+            gu = _sum_bf16(gu, (ctx.H, ctx.C // ctx.H))
+            return (None, None, None, None, gr, gk, gv, gw, gu)
+
+
+def RUN_CUDA_RWKV6(B, T, C, H, r, k, v, w, u):
+    return WKV_6.apply(B, T, C, H, r, k, v, w, u)
+
+
+class WKV_6STATE(torch.autograd.Function):
+    """RWKV_TRAIN_TYPE='states': learnable initial state s [H,N,N] shared by the batch."""
+
+    @staticmethod
+    def forward(ctx, B, T, C, H, r, k, v, w, u, s):
+        with torch.no_grad():
+            _assert_inputs(C, H, r, k, v, w, u, s)
+            ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
+            ctx.save_for_backward(r, k, v, w, u, s)
+            return wkv6_op.forward_ex(r, k, v, w, u, H, s0=s)
+
+    @staticmethod
+    def backward(ctx, gy):
+        with torch.no_grad():
+            assert gy.dtype == torch.bfloat16
+            gy = gy.contiguous()
+            r, k, v, w, u, s = ctx.saved_tensors
+            H, N = ctx.H, ctx.C // ctx.H
+            gr, gk, gv, gw, gu, gs = wkv6_op.backward_ex(r, k, v, w, u, gy, H, s0=s, want_gs=True)
+            return (None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (H, N)), _sum_bf16(gs, (H, N, N)))
+
+
+class WKV_6STATE_INFCTX(torch.autograd.Function):
+    """RWKV_TRAIN_TYPE='infctx': per-sample carried state s [B,H,N,N], overwritten with the final state."""
+
+    @staticmethod
+    def forward(ctx, B, T, C, H, r, k, v, w, u, s):
+        with torch.no_grad():
+            _assert_inputs(C, H, r, k, v, w, u, s)
+            ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
+            s_init = s.clone()
+            ctx.save_for_backward(r, k, v, w, u, s_init)
+            # s <- final state, written through the raw pointer exactly like the reference kernel does
+            return wkv6_op.forward_ex(r, k, v, w, u, H, s0=s_init, s_out=s)
+
+    @staticmethod
+    def backward(ctx, gy):
+        with torch.no_grad():
+            assert gy.dtype == torch.bfloat16
+            gy = gy.contiguous()
+            r, k, v, w, u, s_init = ctx.saved_tensors
+            H, N = ctx.H, ctx.C // ctx.H
+            gr, gk, gv, gw, gu, gs = wkv6_op.backward_ex(r, k, v, w, u, gy, H, s0=s_init, want_gs=True)
+            # the reference sums gs over the batch to [H,N,N] although s is per sample (src/model.py:126);
+            # the per-sample gradient is the mathematically correct one for a per-sample state
+            return (None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (H, N)), gs)
+
+
+def RUN_CUDA_RWKV6_STATE(B, T, C, H, r, k, v, w, u, s):
+    """'states' flavour (src/model.py:184-185): returns y."""
+    return WKV_6STATE.apply(B, T, C, H, r, k, v, w, u, s)
+
+
+def RUN_CUDA_RWKV6_INFCTX(B, T, C, H, r, k, v, w, u, s):
+    """'infctx' flavour (src/model.py:130-132): returns (y, s) with s updated in place."""
+    x = WKV_6STATE_INFCTX.apply(B, T, C, H, r, k, v, w, u, s)
+    return x, s
+
+
+class WKV_6_BI(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, B, T, C, H, mask, r, k, v, w, u):
+        with torch.no_grad():
+            _assert_inputs(C, H, r, k, v, w, u)
+            assert mask.dtype == torch.int
+            assert mask.is_contiguous()
+            ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
+            ctx.mask = mask
+            ctx.save_for_backward(r, k, v, w, u)
+            return wkv6_op.bi_forward_ex(mask, r, k, v, w, u, H)
+
+    @staticmethod
+    def backward(ctx, gy):
+        with torch.no_grad():
+            assert gy.dtype == torch.bfloat16
+            gy = gy.contiguous()
+            r, k, v, w, u = ctx.saved_tensors
+            gr, gk, gv, gw, gu = wkv6_op.bi_backward_ex(ctx.mask, r, k, v, w, u, gy, ctx.H)
+            return (None, None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (ctx.H, ctx.C // ctx.H)))
+
+
+def RUN_CUDA_RWKV6_BI(B, T, C, H, mask, r, k, v, w, u):
+    """cuda/wkv6_bi.py:59-60 (there also called RUN_CUDA_RWKV6)."""
+    return WKV_6_BI.apply(B, T, C, H, mask, r, k, v, w, u)
+
+
+def select_for_train_type(train_type=None):
+    """The reference picks one RUN_CUDA_RWKV6_STATE at import time from os.environ['RWKV_TRAIN_TYPE']
+    (src/model.py:76, 133); missing variables default to '' here instead of raising KeyError (Q10)."""
+    tt = os.environ.get("RWKV_TRAIN_TYPE", "") if train_type is None else train_type
+    if tt == "infctx":
+        return RUN_CUDA_RWKV6_INFCTX
+    if tt == "states":
+        return RUN_CUDA_RWKV6_STATE
+    return RUN_CUDA_RWKV6

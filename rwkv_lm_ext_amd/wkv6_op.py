@@ -1,0 +1,287 @@
+"""Operator layer: the torch-extension surface of cuda/wkv6_op.cpp, cuda/wkv6_bi_op.cpp,
+cuda/wkv6state_op.cpp and cuda/wkv6infctx_op.cpp, served by librwkv6_amd.so.
+
+The reference obtains four module objects from ``torch.utils.cpp_extension.load`` (src/model.py:80-81,
+134-135, 188-189; cuda/wkv6_bi.py:7) and calls ``module.forward(...)`` / ``module.backward(...)`` on
+them with caller-allocated outputs.  The four objects below keep those names, positional signatures,
+in-place output convention and dtypes:
+
+    wkv6_cuda.forward (B,T,C,H, r,k,v, ew[f32], u, y)                              cuda/wkv6_op.cpp:8-10
+    wkv6_cuda.backward(B,T,C,H, r,k,v, ew[f32], u, gy, gr,gk,gv,gw, gu[B,C])       cuda/wkv6_op.cpp:11-13
+    wkv6_bi_cuda.forward / backward: same with `mask` (int32 [B,T]) after H        cuda/wkv6_bi_op.cpp:8-13
+    wkv6state_cuda / wkv6infctx_cuda.forward(B,T,C,H, r,k,v, w[bf16 raw], u, s, y) cuda/wkv6state_op.cpp:8-10
+                                   .backward(..., s, gy, gr,gk,gv,gw, gu, gs)      cuda/wkv6state_op.cpp:11-13
+
+They are also registered as ``torch.ops.wkv6.forward`` etc. (the reference's TORCH_LIBRARY blocks,
+cuda/wkv6_op.cpp:19-22).  Unlike the reference shims (which check nothing) every call validates
+device, dtype, contiguity and shape and launches on the current stream of the tensors' device.
+"""
+import torch
+
+from . import _lib
+
+HEAD_SIZE = 64
+
+
+def _stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _check_tensors(B, T, C, H, named, dtype=torch.bfloat16):
+    dev = None
+    for name, (t, shape, dt) in named.items():
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"{name} must be a tensor")
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be on the GPU (the WKV6 operator has no CPU path)")
+        dev = dev or t.device
+        if t.device != dev:
+            raise RuntimeError(f"{name} is on {t.device}, expected {dev}")
+        if t.dtype != (dt or dtype):
+            raise RuntimeError(f"{name} must be {dt or dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be contiguous")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if C != H * HEAD_SIZE:
+        raise RuntimeError(f"C ({C}) must equal H*{HEAD_SIZE} ({H * HEAD_SIZE})")   # reference: assert(H*_N_ == C)
+    return dev
+
+
+class _Wkv6:
+    """Stand-in for the module object of `load(name="wkv6", ...)` (src/model.py:188-189)."""
+
+    @staticmethod
+    def forward(B, T, C, H, r, k, v, w, u, y):
+        btc = (B, T, C)
+        dev = _check_tensors(B, T, C, H, dict(r=(r, btc, None), k=(k, btc, None), v=(v, btc, None),
+                                              w=(w, btc, torch.float32), u=(u, None, None), y=(y, btc, None)))
+        with torch.cuda.device(dev):
+            rc = _lib.load().wkv6_cuda_forward(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(y),
+                                               _stream_ptr())
+        _lib.check(rc, "wkv6 forward")
+
+    @staticmethod
+    def backward(B, T, C, H, r, k, v, w, u, gy, gr, gk, gv, gw, gu):
+        btc = (B, T, C)
+        dev = _check_tensors(B, T, C, H, dict(
+            r=(r, btc, None), k=(k, btc, None), v=(v, btc, None), w=(w, btc, torch.float32), u=(u, None, None),
+            gy=(gy, btc, None), gr=(gr, btc, None), gk=(gk, btc, None), gv=(gv, btc, None), gw=(gw, btc, None),
+            gu=(gu, (B, C), None)))
+        ws = torch.empty(_lib.load().wkv6_backward_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().wkv6_backward_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), None,
+                                              _ptr(gy), _ptr(gr), _ptr(gk), _ptr(gv), _ptr(gw), _ptr(gu), None,
+                                              _ptr(ws), ws.numel(), _lib.W_EW_F32, _stream_ptr())
+        _lib.check(rc, "wkv6 backward")
+
+
+class _Wkv6Bi:
+    """Stand-in for `load(name="wkv6_bi", ...)` (cuda/wkv6_bi.py:7)."""
+
+    @staticmethod
+    def forward(B, T, C, H, mask, r, k, v, w, u, y):
+        btc = (B, T, C)
+        dev = _check_tensors(B, T, C, H, dict(mask=(mask, (B, T), torch.int32), r=(r, btc, None), k=(k, btc, None),
+                                              v=(v, btc, None), w=(w, btc, torch.float32), u=(u, None, None),
+                                              y=(y, btc, None)))
+        ws = torch.empty(_lib.load().wkv6bi_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().wkv6bi_forward_ex(B, T, C, H, _ptr(mask), None, _ptr(r), _ptr(k), _ptr(v), _ptr(w),
+                                               _ptr(u), _ptr(y), _ptr(ws), ws.numel(), _lib.W_EW_F32, _stream_ptr())
+        _lib.check(rc, "wkv6_bi forward")
+
+    @staticmethod
+    def backward(B, T, C, H, mask, r, k, v, w, u, gy, gr, gk, gv, gw, gu):
+        btc = (B, T, C)
+        dev = _check_tensors(B, T, C, H, dict(
+            mask=(mask, (B, T), torch.int32), r=(r, btc, None), k=(k, btc, None), v=(v, btc, None),
+            w=(w, btc, torch.float32), u=(u, None, None), gy=(gy, btc, None), gr=(gr, btc, None),
+            gk=(gk, btc, None), gv=(gv, btc, None), gw=(gw, btc, None), gu=(gu, (B, C), None)))
+        ws = torch.empty(_lib.load().wkv6bi_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().wkv6bi_backward_ex(B, T, C, H, _ptr(mask), None, _ptr(r), _ptr(k), _ptr(v), _ptr(w),
+                                                _ptr(u), _ptr(gy), _ptr(gr), _ptr(gk), _ptr(gv), _ptr(gw),
+                                                _ptr(gu), _ptr(ws), ws.numel(), _lib.W_EW_F32, _stream_ptr())
+        _lib.check(rc, "wkv6_bi backward")
+
+
+class _Wkv6State:
+    """Stand-in for `load(name="wkv6state", ...)` (src/model.py:134-135); s: bf16 [H,N,N]."""
+    _per_batch = False
+    _name = "wkv6state"
+
+    @classmethod
+    def _s_shape(cls, B, H):
+        return (B, H, HEAD_SIZE, HEAD_SIZE) if cls._per_batch else (H, HEAD_SIZE, HEAD_SIZE)
+
+    @classmethod
+    def forward(cls, B, T, C, H, r, k, v, w, u, s, y):
+        btc = (B, T, C)
+        dev = _check_tensors(B, T, C, H, dict(r=(r, btc, None), k=(k, btc, None), v=(v, btc, None), w=(w, btc, None),
+                                              u=(u, None, None), s=(s, cls._s_shape(B, H), None), y=(y, btc, None)))
+        fn = getattr(_lib.load(), cls._name + "_cuda_forward")
+        with torch.cuda.device(dev):
+            rc = fn(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(s), _ptr(y), _stream_ptr())
+        _lib.check(rc, cls._name + " forward")
+
+    @classmethod
+    def backward(cls, B, T, C, H, r, k, v, w, u, s, gy, gr, gk, gv, gw, gu, gs):
+        btc = (B, T, C)
+        dev = _check_tensors(B, T, C, H, dict(
+            r=(r, btc, None), k=(k, btc, None), v=(v, btc, None), w=(w, btc, None), u=(u, None, None),
+            s=(s, cls._s_shape(B, H), None), gy=(gy, btc, None), gr=(gr, btc, None), gk=(gk, btc, None),
+            gv=(gv, btc, None), gw=(gw, btc, None), gu=(gu, (B, C), None),
+            gs=(gs, (B, H, HEAD_SIZE, HEAD_SIZE), None)))
+        flags = _lib.W_RAW | (_lib.S0_PER_BATCH if cls._per_batch else 0)
+        ws = torch.empty(_lib.load().wkv6_backward_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().wkv6_backward_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(s),
+                                              _ptr(gy), _ptr(gr), _ptr(gk), _ptr(gv), _ptr(gw), _ptr(gu), _ptr(gs),
+                                              _ptr(ws), ws.numel(), flags, _stream_ptr())
+        _lib.check(rc, cls._name + " backward")
+
+
+class _Wkv6Infctx(_Wkv6State):
+    """Stand-in for `load(name="wkv6infctx", ...)` (src/model.py:80-81); s: bf16 [B,H,N,N], the forward
+    overwrites it with the final state (cuda/wkv6infctx_cuda.cu:65-67)."""
+    _per_batch = True
+    _name = "wkv6infctx"
+
+
+wkv6_cuda = _Wkv6
+wkv6_bi_cuda = _Wkv6Bi
+wkv6state_cuda = _Wkv6State
+wkv6infctx_cuda = _Wkv6Infctx
+
+
+# ---- generic entry used by the autograd layer (raw bf16 decay, optional fp32 I/O, explicit state) ----
+def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None):
+    """y = WKV6(r,k,v,w,u[,s0]) with the I/O type of `r` (bf16, or fp32 for numerics tests)."""
+    B, T, C = r.shape
+    io = r.dtype
+    if io not in (torch.bfloat16, torch.float32):
+        raise RuntimeError(f"unsupported I/O dtype {io}")
+    btc = (B, T, C)
+    wdt = torch.float32 if w_is_ew else io
+    named = dict(r=(r, btc, io), k=(k, btc, io), v=(v, btc, io), w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io))
+    flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
+    if s0 is not None:
+        per_batch = s0.dim() == 4
+        named["s0"] = (s0, (B, H, HEAD_SIZE, HEAD_SIZE) if per_batch else (H, HEAD_SIZE, HEAD_SIZE), io)
+        flags |= _lib.S0_PER_BATCH if per_batch else 0
+    if s_out is not None:
+        named["s_out"] = (s_out, (B, H, HEAD_SIZE, HEAD_SIZE), io)
+    if y is None:
+        y = torch.empty(btc, device=r.device, dtype=io)
+    named["y"] = (y, btc, io)
+    dev = _check_tensors(B, T, C, H, named, dtype=io)
+    with torch.cuda.device(dev):
+        rc = _lib.load().wkv6_forward_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(s0),
+                                         _ptr(s_out), _ptr(y), flags, _stream_ptr())
+    _lib.check(rc, "wkv6 forward_ex")
+    return y
+
+
+def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False):
+    """Returns (gr, gk, gv, gw, gu[B,C], gs[B,H,N,N] or None) in the I/O type of `r`."""
+    B, T, C = r.shape
+    io = r.dtype
+    btc = (B, T, C)
+    wdt = torch.float32 if w_is_ew else io
+    named = dict(r=(r, btc, io), k=(k, btc, io), v=(v, btc, io), w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io),
+                 gy=(gy, btc, io))
+    flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
+    if s0 is not None:
+        per_batch = s0.dim() == 4
+        named["s0"] = (s0, (B, H, HEAD_SIZE, HEAD_SIZE) if per_batch else (H, HEAD_SIZE, HEAD_SIZE), io)
+        flags |= _lib.S0_PER_BATCH if per_batch else 0
+    dev = _check_tensors(B, T, C, H, named, dtype=io)
+    gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
+    gu = torch.empty((B, C), device=dev, dtype=io)
+    gs = torch.empty((B, H, HEAD_SIZE, HEAD_SIZE), device=dev, dtype=io) if want_gs else None
+    ws = torch.empty(_lib.load().wkv6_backward_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().wkv6_backward_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(s0),
+                                          _ptr(gy), _ptr(gr), _ptr(gk), _ptr(gv), _ptr(gw), _ptr(gu), _ptr(gs),
+                                          _ptr(ws), ws.numel(), flags, _stream_ptr())
+    _lib.check(rc, "wkv6 backward_ex")
+    return gr, gk, gv, gw, gu, gs
+
+
+def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False):
+    B, T, C = r.shape
+    io = r.dtype
+    btc = (B, T, C)
+    wdt = torch.float32 if w_is_ew else io
+    named = dict(mask=(mask, (B, T), torch.int32), r=(r, btc, io), k=(k, btc, io), v=(v, btc, io),
+                 w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io))
+    flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
+    dev = _check_tensors(B, T, C, H, named, dtype=io)
+    y = torch.empty(btc, device=dev, dtype=io)
+    ws = torch.empty(_lib.load().wkv6bi_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().wkv6bi_forward_ex(B, T, C, H, _ptr(mask), None, _ptr(r), _ptr(k), _ptr(v), _ptr(w),
+                                           _ptr(u), _ptr(y), _ptr(ws), ws.numel(), flags, _stream_ptr())
+    _lib.check(rc, "wkv6_bi forward_ex")
+    return y
+
+
+def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False):
+    B, T, C = r.shape
+    io = r.dtype
+    btc = (B, T, C)
+    wdt = torch.float32 if w_is_ew else io
+    named = dict(mask=(mask, (B, T), torch.int32), r=(r, btc, io), k=(k, btc, io), v=(v, btc, io),
+                 w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io), gy=(gy, btc, io))
+    flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
+    dev = _check_tensors(B, T, C, H, named, dtype=io)
+    gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
+    gu = torch.empty((B, C), device=dev, dtype=io)
+    ws = torch.empty(_lib.load().wkv6bi_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().wkv6bi_backward_ex(B, T, C, H, _ptr(mask), None, _ptr(r), _ptr(k), _ptr(v), _ptr(w),
+                                            _ptr(u), _ptr(gy), _ptr(gr), _ptr(gk), _ptr(gv), _ptr(gw), _ptr(gu),
+                                            _ptr(ws), ws.numel(), flags, _stream_ptr())
+    _lib.check(rc, "wkv6_bi backward_ex")
+    return gr, gk, gv, gw, gu
+
+
+def selftest():
+    """Cross-lane primitive self-test on the current device (0 = pass)."""
+    return _lib.load().wkv6_selftest(_stream_ptr())
+
+
+# ---- torch.ops registration: the TORCH_LIBRARY(wkv6|wkv6bi|wkv6state|wkv6infctx, m) blocks ------------
+def _register():
+    T9 = "Tensor r, Tensor k, Tensor v, Tensor w, Tensor u"
+    defs = {
+        "wkv6": (f"(int B, int T, int C, int H, {T9}, Tensor(a!) y) -> ()",
+                 f"(int B, int T, int C, int H, {T9}, Tensor gy, Tensor(a!) gr, Tensor(b!) gk, Tensor(c!) gv, "
+                 f"Tensor(d!) gw, Tensor(e!) gu) -> ()", _Wkv6),
+        "wkv6bi": (f"(int B, int T, int C, int H, Tensor mask, {T9}, Tensor(a!) y) -> ()",
+                   f"(int B, int T, int C, int H, Tensor mask, {T9}, Tensor gy, Tensor(a!) gr, Tensor(b!) gk, "
+                   f"Tensor(c!) gv, Tensor(d!) gw, Tensor(e!) gu) -> ()", _Wkv6Bi),
+        "wkv6state": (f"(int B, int T, int C, int H, {T9}, Tensor s, Tensor(a!) y) -> ()",
+                      f"(int B, int T, int C, int H, {T9}, Tensor s, Tensor gy, Tensor(a!) gr, Tensor(b!) gk, "
+                      f"Tensor(c!) gv, Tensor(d!) gw, Tensor(e!) gu, Tensor(f!) gs) -> ()", _Wkv6State),
+        "wkv6infctx": (f"(int B, int T, int C, int H, {T9}, Tensor(z!) s, Tensor(a!) y) -> ()",
+                       f"(int B, int T, int C, int H, {T9}, Tensor s, Tensor gy, Tensor(a!) gr, Tensor(b!) gk, "
+                       f"Tensor(c!) gv, Tensor(d!) gw, Tensor(e!) gu, Tensor(f!) gs) -> ()", _Wkv6Infctx),
+    }
+    libs = []
+    for ns, (fwd_schema, bwd_schema, impl) in defs.items():
+        lib = torch.library.Library(ns, "DEF")
+        lib.define("forward" + fwd_schema)
+        lib.define("backward" + bwd_schema)
+        lib.impl("forward", impl.forward, "CUDA")
+        lib.impl("backward", impl.backward, "CUDA")
+        libs.append(lib)
+    return libs
+
+
+_LIBRARIES = _register()

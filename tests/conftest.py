@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def max_norm_err(a, b):
+    """max|a-b| / max|b|  -- the metric every fp32 tolerance in this suite is stated in."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def bf16_round(x):
+    """Round-to-nearest-even to bfloat16, returned as float32 (numpy)."""
+    x = np.ascontiguousarray(x, np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def bf16_report(out, ref):
+    """Compare a bf16 kernel output (as float32) with the fp64/fp32 oracle result.
+
+    Returns (rel_rms, frac_off, max_ulps): error against RNE_bf16(oracle), normalised by the rms of the
+    oracle; fraction of elements that are not the correctly rounded value; largest deviation in bf16 ulps
+    of max(|ref|, 1e-2*max|ref|).
+    """
+    out = np.asarray(out, np.float64)
+    ref = np.asarray(ref, np.float64)
+    want = bf16_round(ref.astype(np.float32)).astype(np.float64)
+    d = out - want
+    rms = np.sqrt(np.mean(ref ** 2)) + 1e-30
+    rel_rms = float(np.sqrt(np.mean(d ** 2)) / rms)
+    frac_off = float(np.mean(d != 0))
+    floor = 1e-2 * np.abs(ref).max() + 1e-30
+    ulp = np.maximum(np.abs(ref), floor) * 2.0 ** -7
+    max_ulps = float((np.abs(d) / ulp).max())
+    return rel_rms, frac_off, max_ulps
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import wkv6_oracle
+    wkv6_oracle.build()
+    return wkv6_oracle

@@ -1,0 +1,287 @@
+"""GPU parity suite (run with -m gpu on an MI355X).  Every call goes through the C ABI of
+librwkv6_amd.so; expected values come from the CPU oracle (oracle/wkv6_oracle.c) and the golden vectors
+that oracle/gen_golden.py captured from the reference's own CPU paths.
+
+Tolerances (stated once, used everywhere):
+  * fp32 I/O mode:   max|out - ref| / max|ref| <= 1e-5                       (north star: 1e-5 fp32)
+  * bf16 I/O mode:   against RNE_bf16(ref): rms(out - RNE(ref)) / rms(ref) <= 1e-3, at most 2 bf16 ulps
+                     off anywhere, and >= 95 % of the elements equal to the correctly rounded value
+                     (north star: 1e-3 bf16; the reference rounds its fp32 result to bf16 the same way)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bf16_report, load_golden, max_norm_err
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5
+BF16_RMS, BF16_ULPS, BF16_EXACT = 1e-3, 2.0, 0.95
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "the gpu suite needs a GPU"
+    from rwkv_lm_ext_amd import wkv6_op
+    assert wkv6_op.selftest() == 0, "cross-lane primitive self-test failed"
+    return wkv6_op
+
+
+def dev(x, dtype):
+    return torch.from_numpy(np.ascontiguousarray(x)).to("cuda", dtype).contiguous()
+
+
+def host(t):
+    return t.detach().float().cpu().numpy()
+
+
+def check(out, ref, io, what):
+    out = host(out)
+    if io == torch.float32:
+        e = max_norm_err(out, ref)
+        assert e <= F32_TOL, f"{what}: fp32 max-normalised error {e:.2e} > {F32_TOL}"
+    else:
+        rms, off, ulps = bf16_report(out, ref)
+        assert rms <= BF16_RMS and ulps <= BF16_ULPS and off <= 1 - BF16_EXACT, \
+            f"{what}: bf16 rel-rms {rms:.2e}, max {ulps:.2f} ulp, {off * 100:.1f}% not correctly rounded"
+
+
+def rand_inputs(seed, B, T, H, kind="stress"):
+    g = torch.Generator().manual_seed(seed)
+    C = H * 64
+    bf = lambda x: x.to(torch.bfloat16).float().numpy()
+    r, k, v = (bf(torch.randn(B, T, C, generator=g) * 0.5) for _ in range(3))
+    if kind == "init":
+        ramp = torch.tensor([-6 + 5 * (n / (C - 1)) ** (0.7 + 1.3 * 0.5) for n in range(C)])
+        w = bf(ramp.view(1, 1, C) + 0.1 * torch.randn(B, T, C, generator=g))
+    else:
+        w = bf(-1.0 + 0.5 * torch.randn(B, T, C, generator=g))
+    u = bf(torch.randn(H, 64, generator=g) * 0.3)
+    gy = bf(torch.randn(B, T, C, generator=g))
+    return r, k, v, w, u, gy
+
+
+IOS = [torch.float32, torch.bfloat16]
+PLAIN = ["wkv6_init", "wkv6_stress", "wkv6_extreme", "wkv6_T1", "wkv6_T2", "wkv6_T3"]
+
+
+@pytest.mark.parametrize("io", IOS, ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", PLAIN)
+def test_golden_plain(ops, name, io):
+    g = load_golden(name)
+    H = g["u"].shape[0]
+    r, k, v, w, u, gy = (dev(g[n], io) for n in ("r", "k", "v", "w", "u", "gy"))
+    check(ops.forward_ex(r, k, v, w, u, H), g["y"], io, name + " y")
+    gr, gk, gv, gw, gu, _ = ops.backward_ex(r, k, v, w, u, gy, H)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+        check(t, g[n], io, f"{name} {n}")
+    # gu: [B,C] per-batch partials (rounded to bf16 in bf16 mode, as the reference ABI prescribes)
+    e = max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"])
+    assert e <= (F32_TOL if io == torch.float32 else 8e-3), f"{name} gu: {e:.2e}"
+
+
+def test_reference_signature_entry_points(ops):
+    """wkv6_cuda.forward/backward with the reference's dtypes: fp32 ew = -exp(w), bf16 everything else
+    (cuda/wkv6_op.cpp:8-13), also through torch.ops.wkv6.*"""
+    g = load_golden("wkv6_stress")
+    B, T, C = g["r"].shape
+    H = g["u"].shape[0]
+    bf = torch.bfloat16
+    r, k, v, u, gy = (dev(g[n], bf) for n in ("r", "k", "v", "u", "gy"))
+    ew = (-torch.exp(dev(g["w"], bf).float())).contiguous()          # src/model.py:210
+    y = torch.empty(B, T, C, device="cuda", dtype=bf)
+    ops.wkv6_cuda.forward(B, T, C, H, r, k, v, ew, u, y)
+    check(y, g["y"], bf, "wkv6_cuda.forward")
+    y2 = torch.empty_like(y)
+    torch.ops.wkv6.forward(B, T, C, H, r, k, v, ew, u, y2)
+    assert torch.equal(y, y2)
+    gr, gk, gv, gw = (torch.empty_like(y) for _ in range(4))
+    gu = torch.empty(B, C, device="cuda", dtype=bf)
+    ops.wkv6_cuda.backward(B, T, C, H, r, k, v, ew, u, gy, gr, gk, gv, gw, gu)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+        check(t, g[n], bf, "wkv6_cuda.backward " + n)
+    with pytest.raises(RuntimeError):                               # stricter than the reference: shape check
+        ops.wkv6_cuda.forward(B, T, C, H + 1, r, k, v, ew, u, y)
+
+
+@pytest.mark.parametrize("io", IOS, ids=["f32", "bf16"])
+def test_golden_state(ops, io):
+    g = load_golden("wkv6_state")
+    H = g["u"].shape[0]
+    r, k, v, w, u, gy, s = (dev(g[n], io) for n in ("r", "k", "v", "w", "u", "gy", "s"))
+    check(ops.forward_ex(r, k, v, w, u, H, s0=s), g["y"], io, "state y")
+    gr, gk, gv, gw, gu, gs = ops.backward_ex(r, k, v, w, u, gy, H, s0=s, want_gs=True)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+        check(t, g[n], io, "state " + n)
+    tol = F32_TOL if io == torch.float32 else 8e-3
+    assert max_norm_err(host(gs).sum(0), g["gs"]) <= tol
+    assert max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"]) <= tol
+    if io == torch.bfloat16:     # the reference-signature module object
+        B, T, C = g["r"].shape
+        y = torch.empty(B, T, C, device="cuda", dtype=io)
+        ops.wkv6state_cuda.forward(B, T, C, H, r, k, v, w, u, s, y)
+        check(y, g["y"], io, "wkv6state_cuda.forward")
+
+
+@pytest.mark.parametrize("io", IOS, ids=["f32", "bf16"])
+def test_golden_infctx(ops, io):
+    g = load_golden("wkv6_infctx")
+    B, T, C = g["r"].shape
+    H = g["u"].shape[0]
+    r, k, v, w, u, gy, s = (dev(g[n], io) for n in ("r", "k", "v", "w", "u", "gy", "s"))
+    s_out = torch.empty_like(s)
+    check(ops.forward_ex(r, k, v, w, u, H, s0=s, s_out=s_out), g["y"], io, "infctx y")
+    check(s_out, g["s_final"], io, "infctx final state")
+    gr, gk, gv, gw, gu, gs = ops.backward_ex(r, k, v, w, u, gy, H, s0=s, want_gs=True)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw), ("gs", gs)):
+        check(t, g[n], io, "infctx " + n)
+    if io == torch.float32:
+        # carried state: 3 chunks of 16 with the state handed on == one 48-token call (fp32 carry is exact)
+        st = s.clone()
+        ys = []
+        for c in range(3):
+            sl = slice(16 * c, 16 * c + 16)
+            ys.append(ops.forward_ex(r[:, sl].contiguous(), k[:, sl].contiguous(), v[:, sl].contiguous(),
+                                     w[:, sl].contiguous(), u, H, s0=st, s_out=st))
+        check(torch.cat(ys, 1), g["y"], io, "infctx chunked y")
+        check(st, g["s_final"], io, "infctx chunked final state")
+    else:
+        s2 = s.clone()                                              # in-place reference ABI
+        y = torch.empty(B, T, C, device="cuda", dtype=io)
+        ops.wkv6infctx_cuda.forward(B, T, C, H, r, k, v, w, u, s2, y)
+        check(y, g["y"], io, "wkv6infctx_cuda.forward")
+        check(s2, g["s_final"], io, "wkv6infctx_cuda.forward state")
+
+
+@pytest.mark.parametrize("io", IOS, ids=["f32", "bf16"])
+def test_golden_bi(ops, io):
+    g = load_golden("wkv6_bi")
+    H = g["u"].shape[0]
+    r, k, v, w, u, gy = (dev(g[n], io) for n in ("r", "k", "v", "w", "u", "gy"))
+    mask = torch.from_numpy(g["mask"]).to("cuda", torch.int32)
+    y = ops.bi_forward_ex(mask, r, k, v, w, u, H)
+    if io == torch.float32:
+        check(y, g["y"], io, "bi y")
+    else:   # two bf16-rounded halves are added (as the reference's `_y[t] += F(y)` does): allow 3 ulps
+        rms, off, ulps = bf16_report(host(y), g["y"])
+        assert rms <= 3e-3 and ulps <= 3.0, (rms, off, ulps)
+    yh = host(y)
+    assert np.all(yh[0, 31:] == 0) and np.all(yh[1, 18:] == 0) and np.all(yh[2, 1:] == 0)   # Q2: zero-filled
+    gr, gk, gv, gw, gu = ops.bi_backward_ex(mask, r, k, v, w, u, gy, H)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+        if io == torch.float32:
+            check(t, g[n], io, "bi " + n)
+        else:
+            rms, off, ulps = bf16_report(host(t), g[n])
+            assert rms <= 3e-3 and ulps <= 3.0, (n, rms, off, ulps)
+        assert np.all(host(t)[1, 18:] == 0)
+    assert max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"]) <= (F32_TOL if io == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("io", IOS, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 300, 3, "stress"), (1, 1000, 2, "init"), (3, 17, 1, "stress")],
+                         ids=["B2T300H3", "B1T1000H2", "B3T17H1"])
+def test_random_vs_oracle(ops, oracle, shape, io):
+    """Ragged lengths (T not a multiple of the 16-token staging batch), several heads/batches."""
+    B, T, H, kind = shape
+    r, k, v, w, u, gy = rand_inputs(100 + T, B, T, H, kind)
+    d = [dev(x, io) for x in (r, k, v, w, u, gy)]
+    check(ops.forward_ex(*d[:5], H), oracle.forward(r, k, v, w, u), io, "y")
+    og = oracle.backward(r, k, v, w, u, gy)
+    gr, gk, gv, gw, gu, _ = ops.backward_ex(*d[:5], d[5], H)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+        check(t, og[n], io, n)
+    assert max_norm_err(host(gu), og["gu_b"]) <= (F32_TOL if io == torch.float32 else 8e-3)
+
+
+def test_autograd_surface(ops, oracle):
+    """WKV_6.apply / RUN_CUDA_RWKV6 / WKV_6STATE / infctx / WKV_6_BI: gradient tuple order and values."""
+    from rwkv_lm_ext_amd.wkv import (RUN_CUDA_RWKV6, RUN_CUDA_RWKV6_BI, RUN_CUDA_RWKV6_INFCTX,
+                                     RUN_CUDA_RWKV6_STATE)
+    bf = torch.bfloat16
+    B, T, H = 2, 64, 2
+    C = H * 64
+    r, k, v, w, u, gy = rand_inputs(5, B, T, H)
+    leaves = [dev(x, bf).requires_grad_(True) for x in (r, k, v, w, u)]
+    y = RUN_CUDA_RWKV6(B, T, C, H, *leaves)
+    y.backward(dev(gy, bf))
+    og = oracle.backward(r, k, v, w, u, gy)
+    check(y, oracle.forward(r, k, v, w, u), bf, "RUN_CUDA_RWKV6 y")
+    for t, n in zip(leaves, ("gr", "gk", "gv", "gw")):
+        check(t.grad, og[n], bf, "autograd " + n)
+    assert leaves[4].grad.shape == (H, 64) and leaves[4].grad.dtype == bf
+    assert max_norm_err(host(leaves[4].grad), og["gu"]) <= 8e-3
+
+    g = torch.Generator().manual_seed(9)
+    s = (torch.randn(H, 64, 64, generator=g) * 0.5).to(bf).float().numpy()
+    leaves = [dev(x, bf).requires_grad_(True) for x in (r, k, v, w, u, s)]
+    y = RUN_CUDA_RWKV6_STATE(B, T, C, H, *leaves)
+    y.backward(dev(gy, bf))
+    og = oracle.backward(r, k, v, w, u, gy, s)
+    check(y, oracle.forward(r, k, v, w, u, s), bf, "states y")
+    assert leaves[5].grad.shape == (H, 64, 64)
+    assert max_norm_err(host(leaves[5].grad), og["gs"]) <= 8e-3
+
+    sb = (torch.randn(B, H, 64, 64, generator=g) * 0.5).to(bf).float().numpy()
+    leaves = [dev(x, bf).requires_grad_(True) for x in (r, k, v, w, u)]
+    st = dev(sb, bf)
+    y, st2 = RUN_CUDA_RWKV6_INFCTX(B, T, C, H, *leaves, st)
+    assert st2 is st                                                    # updated in place, returned
+    yo, so = oracle.forward(r, k, v, w, u, sb, return_state=True)
+    check(y, yo, bf, "infctx y")
+    check(st, so, bf, "infctx state")
+    y.backward(dev(gy, bf))
+    check(leaves[0].grad, oracle.backward(r, k, v, w, u, gy, sb)["gr"], bf, "infctx gr (initial state kept, Q6)")
+
+    mask = torch.ones(B, T, dtype=torch.int32)
+    mask[0, 40:] = 0
+    leaves = [dev(x, bf).requires_grad_(True) for x in (r, k, v, w, u)]
+    y = RUN_CUDA_RWKV6_BI(B, T, C, H, mask.cuda(), *leaves)
+    y.backward(dev(gy, bf))
+    rms, _, ulps = bf16_report(host(y), oracle.bi_forward(mask.numpy(), r, k, v, w, u))
+    assert rms <= 3e-3 and ulps <= 3
+    ob = oracle.bi_backward(mask.numpy(), r, k, v, w, u, gy)
+    rms, _, ulps = bf16_report(host(leaves[1].grad), ob["gk"])
+    assert rms <= 3e-3 and ulps <= 3
+
+
+def test_full_size_properties(ops):
+    """BASELINE config 2 (B=8,T=4096,C=2048,H=32), where the CPU oracle would take minutes: properties
+    that do not depend on size.  (a) splitting the sequence and carrying the fp32 state reproduces the
+    single call; (b) y is linear in v; (c) the oracle on one (b,h) slice of the big problem."""
+    from oracle import wkv6_oracle as orc
+    B, T, H = 8, 4096, 32
+    C = H * 64
+    g = torch.Generator(device="cuda").manual_seed(0)
+    f32 = torch.float32
+    r, k, v = (torch.randn(B, T, C, device="cuda", generator=g).mul_(0.5).to(torch.bfloat16).to(f32) for _ in range(3))
+    ramp = torch.tensor([-6 + 5 * (n / (C - 1)) ** (0.7 + 1.3 * 0.5) for n in range(C)], device="cuda")
+    w = (ramp.view(1, 1, C) + 0.1 * torch.randn(B, T, C, device="cuda", generator=g)).to(torch.bfloat16).to(f32)
+    u = (torch.randn(H, 64, device="cuda", generator=g) * 0.3).to(torch.bfloat16).to(f32)
+    y = ops.forward_ex(r, k, v, w, u, H)
+    # (a) 2 x 2048 with carried state
+    st = torch.zeros(B, H, 64, 64, device="cuda")
+    parts = []
+    for c in range(2):
+        sl = slice(2048 * c, 2048 * (c + 1))
+        parts.append(ops.forward_ex(*(x[:, sl].contiguous() for x in (r, k, v, w)), u, H, s0=st, s_out=st))
+    assert max_norm_err(host(torch.cat(parts, 1)), host(y)) <= F32_TOL
+    # (b) linearity in v
+    v2 = torch.randn(B, T, C, device="cuda", generator=g).to(torch.bfloat16).to(f32)
+    y2 = ops.forward_ex(r, k, v2, w, u, H)
+    y12 = ops.forward_ex(r, k, v + 2 * v2, w, u, H)
+    assert max_norm_err(host(y12), host(y + 2 * y2)) <= F32_TOL
+    # (c) one head of one batch row against the oracle (fwd + bwd), full length
+    b, h = 5, 17
+    sl = (slice(b, b + 1), slice(None), slice(64 * h, 64 * h + 64))
+    rs, ks, vs, ws = (host(x[sl]) for x in (r, k, v, w))
+    us = host(u[h:h + 1])
+    assert max_norm_err(host(y[sl]), orc.forward(rs, ks, vs, ws, us)) <= F32_TOL
+    gy = torch.randn(B, T, C, device="cuda", generator=g).to(torch.bfloat16).to(f32)
+    gr, gk, gv, gw, gu, _ = ops.backward_ex(r, k, v, w, u, gy, H)
+    og = orc.backward(rs, ks, vs, ws, us, host(gy[sl]))
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+        e = max_norm_err(host(t[sl]), og[n])
+        assert e <= (5e-5 if n == "gw" else F32_TOL), (n, e)       # gw: 4096-term suffix sums in fp32
+    assert max_norm_err(host(gu[b, 64 * h:64 * h + 64]), og["gu_b"][0]) <= 5e-5
