@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""WKV6 fwd+bwd micro-benchmark on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wkv6|infctx|bi] [--no-cpu]
+
+One "step" = one forward + one backward of the WKV6 operator through the C ABI of librwkv6_amd.so on one
+batch of synthetic bf16 inputs that already live in HBM (BASELINE.json configs[1]: B=8, T=4096, C=2048,
+H=32).  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs the same
+per-GPU workload -- the path shards over the batch with no data-path collective -- and the
+reported value is the whole-job rate: N * tokens / max-over-ranks time.  Rank 0 prints ONE JSON line.
+
+Algorithmic bytes: forward reads r,k,v,w and writes y = 10 B per token-channel, backward
+reads r,k,v,w,gy and writes gr,gk,gv,gw = 18 B; 28 B per token-channel for the step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FWD_BYTES, BWD_BYTES = 10, 18   # per token-channel
+
+
+def synth(B, T, H, device, seed=0):
+    """SURVEY.md 8d synthetic inputs: r,k,v ~ N(0,1)*0.5, w = model decay-init ramp + N(0,0.1^2), u ~ N(0,0.3^2)."""
+    C = H * 64
+    g = torch.Generator(device=device).manual_seed(seed)
+    bf = torch.bfloat16
+    r, k, v = (torch.randn(B, T, C, device=device, generator=g).mul_(0.5).to(bf) for _ in range(3))
+    ramp = torch.tensor([-6 + 5 * (n / (C - 1)) ** (0.7 + 1.3 * 0.5) for n in range(C)], device=device)
+    w = (ramp.view(1, 1, C) + 0.1 * torch.randn(B, T, C, device=device, generator=g)).to(bf)
+    u = (torch.randn(H, 64, device=device, generator=g) * 0.3).to(bf)
+    gy = torch.randn(B, T, C, device=device, generator=g).to(bf)
+    return r, k, v, w, u, gy
+
+
+def cpu_baseline(budget_s=20.0):
+    """The reference's pure-PyTorch CPU algorithm (fla naive recurrence + autograd), restated in
+    oracle/wkv6_torch_naive.py, timed on the host cores at BASELINE config 1's shape."""
+    from oracle.wkv6_torch_naive import wkv6_naive_fwd_bwd
+    B, T, H = 2, 128, 32
+    C = H * 64
+    g = torch.Generator().manual_seed(0)
+    r, k, v = (torch.randn(B, T, C, generator=g) * 0.5 for _ in range(3))
+    w = -1.0 + 0.5 * torch.randn(B, T, C, generator=g)
+    u = torch.randn(H, 64, generator=g) * 0.3
+    gy = torch.randn(B, T, C, generator=g)
+    wkv6_naive_fwd_bwd(r[:, :8], k[:, :8], v[:, :8], w[:, :8], u, gy[:, :8])      # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        wkv6_naive_fwd_bwd(r, k, v, w, u, gy)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 8:
+            break
+    return {"value": round(B * T * reps / el, 1), "unit": "tokens/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{reps} x (fwd + autograd bwd), fp32, B={B} T={T} C={C} H={H} (BASELINE config 1 shape), "
+                      f"{el:.1f} s on {os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="wkv6", choices=["wkv6", "infctx", "bi"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the WKV6 operator has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rwkv_lm_ext_amd import wkv6_op
+
+    if args.workload == "wkv6":
+        B, T, H = 8, 4096, 32
+        name = "wkv6_fwd_bwd B=8 T=4096 C=2048 H=32 (BASELINE configs[1])"
+    elif args.workload == "infctx":
+        B, T, H = 4, 16384, 32
+        name = "wkv6infctx fwd+bwd B=4 T=16384 in 8 chunks of 2048, bf16 state carry (BASELINE configs[4])"
+    else:
+        B, T, H = 48, 512, 32
+        name = "wkv6_bi fwd+bwd B=48 (16x3) T=512, mask lengths U[64,512] (BASELINE configs[2])"
+    C = H * 64
+    r, k, v, w, u, gy = synth(B, T, H, dev, seed=rank)
+    tokens = B * T
+
+    if args.workload == "wkv6":
+        y = torch.empty_like(r)
+
+        def fwd():
+            wkv6_op.forward_ex(r, k, v, w, u, H, y=y)
+
+        def bwd():
+            wkv6_op.backward_ex(r, k, v, w, u, gy, H)
+    elif args.workload == "infctx":
+        chunks = [slice(2048 * c, 2048 * (c + 1)) for c in range(8)]
+        parts = [[x[:, sl].contiguous() for x in (r, k, v, w, gy)] for sl in chunks]
+        states = [torch.zeros(B, H, 64, 64, device=dev, dtype=torch.bfloat16) for _ in range(9)]
+
+        def fwd():
+            for c, (rc, kc, vc, wc, _) in enumerate(parts):
+                wkv6_op.forward_ex(rc, kc, vc, wc, u, H, s0=states[c], s_out=states[c + 1])
+
+        def bwd():      # truncated BPTT as the reference trains it: each chunk's backward from its entry state
+            for c, (rc, kc, vc, wc, gc) in enumerate(parts):
+                wkv6_op.backward_ex(rc, kc, vc, wc, u, gc, H, s0=states[c], want_gs=True)
+    else:
+        g = torch.Generator(device=dev).manual_seed(1)
+        lens = torch.randint(64, 513, (B,), device=dev, generator=g)
+        mask = (torch.arange(T, device=dev).view(1, T) < (lens.view(B, 1) - 1)).to(torch.int32).contiguous()
+        tokens = int(lens.clamp(max=T).sum().item())
+
+        def fwd():
+            wkv6_op.bi_forward_ex(mask, r, k, v, w, u, H)
+
+        def bwd():
+            wkv6_op.bi_backward_ex(mask, r, k, v, w, u, gy, H)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fwd()
+        bwd()
+    sync_all()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()
+        fwd()
+        ev[s][1].record()
+        bwd()
+        ev[s][2].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sync_all()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        units = tokens * C                                    # token-channels per step per GPU
+        dom_name, dom_ms, dom_b = ("backward", bwd_ms, BWD_BYTES) if bwd_ms >= fwd_ms else ("forward", fwd_ms, FWD_BYTES)
+        ach = units * dom_b / (dom_ms * 1e-3) / 1e9
+        step_ach = units * (FWD_BYTES + BWD_BYTES) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
+        out = {
+            "metric": "WKV6 fwd+bwd tokens/sec/GPU (B=8,T=4096,C=2048) + %HBM roofline",
+            "value": round(world * tokens * args.steps / elapsed, 1),
+            "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "io": "bf16", "tokens_per_gpu": tokens, "channels": C,
+                       "parallelism": f"dp{world} (independent batches per GPU, no data-path collective)",
+                       "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4)},
+            "roofline": {"bound": "hbm", "kernel": dom_name,
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": units * dom_b, "avg_ms": round(dom_ms, 4)},
+            "roofline_step": {"bound": "hbm", "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round(step_ach / HBM_PEAK_GBPS, 4),
+                              "algorithmic_bytes": units * (FWD_BYTES + BWD_BYTES)},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,7 +89,8 @@ int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, c
                      const void* w, const void* u, const void* s0, const void* gy, void* gr,
                      void* gk, void* gv, void* gw, void* gu, void* gs, void* workspace,
                      size_t workspace_bytes, unsigned flags, void* stream);
-/* lens: int32 [B] device array, number of leading tokens both scans cover (NULL: derive from mask). */
+/* lens: int32 [B] device array, number of leading tokens both scans cover (NULL: derive from mask).
+ * workspace: wkv6bi_workspace_bytes() bytes (NULL: library-owned buffer). */
 int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
                       const void* k, const void* v, const void* w, const void* u, void* y,
                       void* workspace, size_t workspace_bytes, unsigned flags, void* stream);

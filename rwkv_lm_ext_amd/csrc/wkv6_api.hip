@@ -137,20 +137,22 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
     if (int rc = check_shape(B, T, C, H)) return rc;
     if (!r || !k || !v || !w || !u || !y || (!mask && !lens)) return WKV6_ENULL;
     hipStream_t st = (hipStream_t)stream;
+    const size_t need = wkv6bi_workspace_bytes(B, T, C, H);
+    if (!workspace) {
+        workspace = internal_scratch(need);
+        if (!workspace) return WKV6_EWORKSPACE;
+    } else if (workspace_bytes < need) {
+        return WKV6_EWORKSPACE;
+    }
+    float* yf32 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * sizeof(int)));
     if (!lens) {
-        const size_t need = align_up((size_t)B * sizeof(int));
-        if (!workspace) {
-            workspace = internal_scratch(wkv6bi_workspace_bytes(B, T, C, H));
-            if (!workspace) return WKV6_EWORKSPACE;
-        } else if (workspace_bytes < need) {
-            return WKV6_EWORKSPACE;
-        }
         int* l = reinterpret_cast<int*>(workspace);
         hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, l, T);
         lens = l;
     }
     ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
     a.y = y;
+    a.y_f32 = yf32;                           // the two halves are summed in fp32 and rounded once
     a.lens = lens;
     a.zero_tail = 1;                          // y[t > L_b] = 0 (the reference leaves it uninitialised, Q2)
     if (hipError_t e = launch_scan_fwd(a, flags & WKV6_IO_F32, st)) return (int)e;

@@ -30,6 +30,8 @@ struct ScanArgs {
     long s0_bstride;                  // elements between batch entries of s0 (0: shared over the batch)
     void* s_out;                      // final state [B,H,N,N] in the I/O type, or null   (forward only)
     void* y;                          // forward output
+    float* y_f32;                     // optional fp32 side buffer [B,T,C]: written INSTEAD of y when accumulate == 0,
+                                      // read as the addend (instead of y) when accumulate == 1  (wkv6_bi halves)
     const void* gy;                   // backward input
     void *gr, *gk, *gv, *gw;          // backward outputs, I/O type
     void* gu;                         // [B,C] per-batch partials, I/O type (null: skip)

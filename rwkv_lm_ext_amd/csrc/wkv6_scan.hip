@@ -215,11 +215,13 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanArgs a)
                 lds_load<CPT>(ys + buf * TB * ROW + spp * ROW + sc0, o);
                 if (a.accumulate) {
                     float old[CPT];
-                    ion<T, CPT>::load(gy_ + idx, old);
+                    if (a.y_f32) lds_load<CPT>(a.y_f32 + idx, old);
+                    else ion<T, CPT>::load(gy_ + idx, old);
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) o[c] += old[c];
                 }
-                ion<T, CPT>::store(gy_ + idx, o);
+                if (a.y_f32 && !a.accumulate) lds_store<CPT>(a.y_f32 + idx, o);
+                else ion<T, CPT>::store(gy_ + idx, o);
             }
         }
     }

@@ -39,7 +39,9 @@ def host(t):
 def check(out, ref, io, what):
     out = host(out)
     if io == torch.float32:
-        e = max_norm_err(out, ref)
+        # gw is a difference of O(1) suffix sums (a_s - b_s); when the true value is ~0 (T <= 2: exactly 0)
+        # the fp32 cancellation residue must be measured against those terms, not against max|ref| = 0
+        e = max_norm_err(out, ref, floor=0.1 if what.endswith("gw") else 1e-3)
         assert e <= F32_TOL, f"{what}: fp32 max-normalised error {e:.2e} > {F32_TOL}"
     else:
         rms, off, ulps = bf16_report(out, ref)
@@ -161,20 +163,16 @@ def test_golden_bi(ops, io):
     r, k, v, w, u, gy = (dev(g[n], io) for n in ("r", "k", "v", "w", "u", "gy"))
     mask = torch.from_numpy(g["mask"]).to("cuda", torch.int32)
     y = ops.bi_forward_ex(mask, r, k, v, w, u, H)
-    if io == torch.float32:
-        check(y, g["y"], io, "bi y")
-    else:   # two bf16-rounded halves are added (as the reference's `_y[t] += F(y)` does): allow 3 ulps
-        rms, off, ulps = bf16_report(host(y), g["y"])
-        assert rms <= 3e-3 and ulps <= 3.0, (rms, off, ulps)
+    check(y, g["y"], io, "bi y")         # the two halves are summed in fp32 and rounded once
     yh = host(y)
     assert np.all(yh[0, 31:] == 0) and np.all(yh[1, 18:] == 0) and np.all(yh[2, 1:] == 0)   # Q2: zero-filled
     gr, gk, gv, gw, gu = ops.bi_backward_ex(mask, r, k, v, w, u, gy, H)
     for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
         if io == torch.float32:
             check(t, g[n], io, "bi " + n)
-        else:
-            rms, off, ulps = bf16_report(host(t), g[n])
-            assert rms <= 3e-3 and ulps <= 3.0, (n, rms, off, ulps)
+        else:   # the adjoints of the two scans are accumulated in the bf16 output (like the reference's
+            # `_gr[t] += F(gr)`, cuda/wkv6_bi_cuda.cu:199-200): each half is rounded once -> <= 8e-3 of max
+            assert max_norm_err(host(t), g[n]) <= 8e-3, n
         assert np.all(host(t)[1, 18:] == 0)
     assert max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"]) <= (F32_TOL if io == torch.float32 else 8e-3)
 
@@ -239,11 +237,9 @@ def test_autograd_surface(ops, oracle):
     leaves = [dev(x, bf).requires_grad_(True) for x in (r, k, v, w, u)]
     y = RUN_CUDA_RWKV6_BI(B, T, C, H, mask.cuda(), *leaves)
     y.backward(dev(gy, bf))
-    rms, _, ulps = bf16_report(host(y), oracle.bi_forward(mask.numpy(), r, k, v, w, u))
-    assert rms <= 3e-3 and ulps <= 3
+    check(y, oracle.bi_forward(mask.numpy(), r, k, v, w, u), bf, "WKV_6_BI y")
     ob = oracle.bi_backward(mask.numpy(), r, k, v, w, u, gy)
-    rms, _, ulps = bf16_report(host(leaves[1].grad), ob["gk"])
-    assert rms <= 3e-3 and ulps <= 3
+    assert max_norm_err(host(leaves[1].grad), ob["gk"]) <= 8e-3
 
 
 def test_full_size_properties(ops):
