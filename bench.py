@@ -134,30 +134,23 @@ def main():
         def bwd():
             wkv6_op.bi_backward_ex(mask, r, k, v, w, u, gy, H)
 
-    def sync_all():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        fwd()
-        bwd()
-    sync_all()
+    from rwkv_lm_ext_amd.dp import timed_steps
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        ev[s][0].record()
+    counter = {"i": -args.warmup}
+
+    def step():                       # HIP events on the launch stream bracket fwd and bwd of every timed step
+        i = counter["i"]
+        counter["i"] += 1
+        if i >= 0:
+            ev[i][0].record()
         fwd()
-        ev[s][1].record()
+        if i >= 0:
+            ev[i][1].record()
         bwd()
-        ev[s][2].record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    sync_all()
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if i >= 0:
+            ev[i][2].record()
+
+    elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
 
