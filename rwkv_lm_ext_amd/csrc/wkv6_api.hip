@@ -67,6 +67,13 @@ __global__ void mask_to_lens_kernel(const int* __restrict__ mask, int* __restric
 
 int to_rc(hipError_t e) { return e == hipSuccess ? WKV6_OK : (int)e; }
 
+// forward dispatch: chunked MFMA kernel for bf16 I/O unless the caller forces the exact scan
+hipError_t run_fwd(const ScanArgs& a, unsigned flags, hipStream_t st)
+{
+    if ((flags & WKV6_IO_F32) || (flags & WKV6_ALGO_SCAN)) return launch_scan_fwd(a, flags & WKV6_IO_F32, st);
+    return launch_chunk_fwd(a, st);
+}
+
 ScanArgs base_args(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                    const void* w, const void* u, unsigned flags)
 {
@@ -105,7 +112,7 @@ int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, co
     a.s0_bstride = (flags & WKV6_S0_PER_BATCH) ? (long)H * HEAD * HEAD : 0;
     a.s_out = s_out;
     a.y = y;
-    return to_rc(launch_scan_fwd(a, flags & WKV6_IO_F32, (hipStream_t)stream));
+    return to_rc(run_fwd(a, flags, (hipStream_t)stream));
 }
 
 int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
@@ -155,9 +162,9 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
     a.y_f32 = yf32;                           // the two halves are summed in fp32 and rounded once
     a.lens = lens;
     a.zero_tail = 1;                          // y[t > L_b] = 0 (the reference leaves it uninitialised, Q2)
-    if (hipError_t e = launch_scan_fwd(a, flags & WKV6_IO_F32, st)) return (int)e;
+    if (hipError_t e = run_fwd(a, flags, st)) return (int)e;
     a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0;   // cuda/wkv6_bi_cuda.cu:71-111
-    return to_rc(launch_scan_fwd(a, flags & WKV6_IO_F32, st));
+    return to_rc(run_fwd(a, flags, st));
 }
 
 int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,

@@ -47,5 +47,7 @@ struct ScanArgs {
 hipError_t launch_scan_fwd(const ScanArgs& a, bool io_f32, hipStream_t st);
 hipError_t launch_scan_bwd(const ScanArgs& a, bool io_f32, hipStream_t st);
 hipError_t launch_selftest(int* result, hipStream_t st);
+// chunked MFMA forward (bf16 I/O only), wkv6_chunk.hip
+hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st);
 
 }  // namespace wkv6

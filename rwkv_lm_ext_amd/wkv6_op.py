@@ -160,8 +160,9 @@ wkv6infctx_cuda = _Wkv6Infctx
 
 
 # ---- generic entry used by the autograd layer (raw bf16 decay, optional fp32 I/O, explicit state) ----
-def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None):
-    """y = WKV6(r,k,v,w,u[,s0]) with the I/O type of `r` (bf16, or fp32 for numerics tests)."""
+def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None, algo=None):
+    """y = WKV6(r,k,v,w,u[,s0]) with the I/O type of `r` (bf16, or fp32 for numerics tests).
+    algo: None (library default: chunked MFMA kernel for bf16 I/O) or "scan" (exact token-serial kernels)."""
     B, T, C = r.shape
     io = r.dtype
     if io not in (torch.bfloat16, torch.float32):
@@ -170,6 +171,7 @@ def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None):
     wdt = torch.float32 if w_is_ew else io
     named = dict(r=(r, btc, io), k=(k, btc, io), v=(v, btc, io), w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io))
     flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
+    flags |= _lib.ALGO_SCAN if algo == "scan" else 0
     if s0 is not None:
         per_batch = s0.dim() == 4
         named["s0"] = (s0, (B, H, HEAD_SIZE, HEAD_SIZE) if per_batch else (H, HEAD_SIZE, HEAD_SIZE), io)
@@ -213,7 +215,7 @@ def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False):
     return gr, gk, gv, gw, gu, gs
 
 
-def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False):
+def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None):
     B, T, C = r.shape
     io = r.dtype
     btc = (B, T, C)
@@ -221,6 +223,7 @@ def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False):
     named = dict(mask=(mask, (B, T), torch.int32), r=(r, btc, io), k=(k, btc, io), v=(v, btc, io),
                  w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io))
     flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
+    flags |= _lib.ALGO_SCAN if algo == "scan" else 0
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     y = torch.empty(btc, device=dev, dtype=io)
     ws = torch.empty(_lib.load().wkv6bi_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
