@@ -74,6 +74,16 @@ hipError_t run_fwd(const ScanArgs& a, unsigned flags, hipStream_t st)
     return launch_chunk_fwd(a, st);
 }
 
+hipError_t run_bwd(ScanArgs& a, unsigned flags, float* scratch, hipStream_t st)
+{
+    if ((flags & WKV6_IO_F32) || (flags & WKV6_ALGO_SCAN)) {
+        a.aux = scratch;
+        return launch_scan_bwd(a, flags & WKV6_IO_F32, st);
+    }
+    a.ckpt = scratch;
+    return launch_chunk_bwd(a, st);
+}
+
 ScanArgs base_args(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                    const void* w, const void* u, unsigned flags)
 {
@@ -93,8 +103,10 @@ const char* wkv6_amd_version(void) { return "0.1"; }
 
 size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H)
 {
-    (void)H;
-    return align_up((size_t)B * T * C * sizeof(float));
+    // scan path: one fp32 [B,T,C] array; chunked path: one fp32 64x64 state per 64-token group (>= the former)
+    const size_t scan = (size_t)B * T * C * sizeof(float);
+    const size_t chunk = chunk_ckpt_floats(B, T, H) * sizeof(float);
+    return align_up(scan > chunk ? scan : chunk);
 }
 size_t wkv6bi_workspace_bytes(int B, int T, int C, int H)
 {
@@ -133,8 +145,7 @@ int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, c
     a.s0 = s0;
     a.s0_bstride = (flags & WKV6_S0_PER_BATCH) ? (long)H * HEAD * HEAD : 0;
     a.gy = gy; a.gr = gr; a.gk = gk; a.gv = gv; a.gw = gw; a.gu = gu; a.gs = gs;
-    a.aux = reinterpret_cast<float*>(workspace);
-    return to_rc(launch_scan_bwd(a, flags & WKV6_IO_F32, (hipStream_t)stream));
+    return to_rc(run_bwd(a, flags, reinterpret_cast<float*>(workspace), (hipStream_t)stream));
 }
 
 int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
@@ -190,12 +201,11 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
     }
     ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
     a.gy = gy; a.gr = gr; a.gk = gk; a.gv = gv; a.gw = gw; a.gu = gu;
-    a.aux = aux;
     a.lens = lens;
     a.zero_tail = 1;
-    if (hipError_t e = launch_scan_bwd(a, flags & WKV6_IO_F32, st)) return (int)e;   // adjoint of the forward scan
+    if (hipError_t e = run_bwd(a, flags, aux, st)) return (int)e;                    // adjoint of the forward scan
     a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0; a.gu = nullptr;   // adjoint of the reverse scan
-    return to_rc(launch_scan_bwd(a, flags & WKV6_IO_F32, st));
+    return to_rc(run_bwd(a, flags, aux, st));
 }
 
 // ---- reference-signature entry points ------------------------------------------------------------

@@ -1,0 +1,56 @@
+// Shared definitions of the chunked MFMA kernels (wkv6_chunk.hip, wkv6_chunk_bwd.hip).
+#pragma once
+#include "wkv6_scan.h"
+
+namespace wkv6 {
+namespace chunk {
+
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef __bf16 b8v __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int BLK = 16;                       // tokens per block
+constexpr int NBLK = 4;                       // blocks per group (= waves)
+constexpr int GRP = BLK * NBLK;               // 64 tokens per group
+constexpr int RSB = 144;                      // bytes per staged token row (64 bf16 + 8 pad): conflict-free b128 reads
+constexpr int ARR = BLK * RSB;                // one operand array
+enum { A_RH = 0, A_RL, A_KH, A_KL, A_ZRH, A_ZRL, A_ZKH, A_ZKL, A_V, N_ARR };
+constexpr int OFF_D = N_ARR * ARR;            // float[64]  e^{c_16}
+constexpr int OFF_COEF = OFF_D + 64 * 4;      // float[16]  sum_i r u k
+constexpr int BLK_BYTES = OFF_COEF + 16 * 4;  // 21056
+constexpr float LW_MIN = -9.0f;
+
+__device__ __forceinline__ s4v tr_read(const char* p)
+{   // ds_read_b64_tr_b16: lane x of each 16-lane group receives column x of a 4-row x 16-column block whose
+    // row q / columns 4p..4p+3 are addressed by lane 4q+p of the group
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s4v __attribute__((address_space(3)))*)(const_cast<char*>(p)));
+}
+__device__ __forceinline__ f4v mfma16(s4v a, s4v b, f4v c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f4v mfma32(b8v a, b8v b, f4v c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ b8v ld_b8(const char* p) { return *reinterpret_cast<const b8v*>(p); }
+__device__ __forceinline__ b8v ld_b8_2x4(const char* p0, const char* p1)
+{
+    const uint2 a = *reinterpret_cast<const uint2*>(p0);
+    const uint2 b = *reinterpret_cast<const uint2*>(p1);
+    const uint4 v = make_uint4(a.x, a.y, b.x, b.y);
+    return __builtin_bit_cast(b8v, v);
+}
+// split 4 floats into packed bf16 hi and lo parts
+__device__ __forceinline__ void split4(const float (&x)[4], uint2& hi, uint2& lo)
+{
+    hi.x = pack_bf2(x[0], x[1]);
+    hi.y = pack_bf2(x[2], x[3]);
+    lo.x = pack_bf2(x[0] - bf_lo(hi.x), x[1] - bf_hi(hi.x));
+    lo.y = pack_bf2(x[2] - bf_lo(hi.y), x[3] - bf_hi(hi.y));
+}
+
+
+}  // namespace chunk
+}  // namespace wkv6

@@ -28,58 +28,16 @@
 //
 // Decays smaller than e^LW_MIN per token are clamped (their true effect on any output is < 1.3e-4 of the
 // carried state, far below bf16 output resolution); the exact scan kernels remain available (WKV6_ALGO_SCAN).
-#include "wkv6_scan.h"
+#include "wkv6_chunk.h"
 
 namespace wkv6 {
 namespace {
 
-typedef short s4v __attribute__((ext_vector_type(4)));
-typedef __bf16 b8v __attribute__((ext_vector_type(8)));
-typedef float f4v __attribute__((ext_vector_type(4)));
+using namespace chunk;
 
-constexpr int BLK = 16;                       // tokens per block
-constexpr int NBLK = 4;                       // blocks per group (= waves)
-constexpr int GRP = BLK * NBLK;               // 64 tokens per group
-constexpr int RSB = 144;                      // bytes per staged token row (64 bf16 + 8 pad): conflict-free b128 reads
-constexpr int ARR = BLK * RSB;                // one operand array
-enum { A_RH = 0, A_RL, A_KH, A_KL, A_ZRH, A_ZRL, A_ZKH, A_ZKL, A_V, N_ARR };
-constexpr int OFF_D = N_ARR * ARR;            // float[64]  e^{c_16}
-constexpr int OFF_COEF = OFF_D + 64 * 4;      // float[16]  sum_i r u k
-constexpr int BLK_BYTES = OFF_COEF + 16 * 4;  // 21056
-constexpr float LW_MIN = -9.0f;
-
-__device__ __forceinline__ s4v tr_read(const char* p)
-{   // ds_read_b64_tr_b16: lane x of each 16-lane group receives column x of a 4-row x 16-column block whose
-    // row q / columns 4p..4p+3 are addressed by lane 4q+p of the group
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (s4v __attribute__((address_space(3)))*)(const_cast<char*>(p)));
-}
-__device__ __forceinline__ f4v mfma16(s4v a, s4v b, f4v c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f4v mfma32(b8v a, b8v b, f4v c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ b8v ld_b8(const char* p) { return *reinterpret_cast<const b8v*>(p); }
-__device__ __forceinline__ b8v ld_b8_2x4(const char* p0, const char* p1)
-{
-    const uint2 a = *reinterpret_cast<const uint2*>(p0);
-    const uint2 b = *reinterpret_cast<const uint2*>(p1);
-    const uint4 v = make_uint4(a.x, a.y, b.x, b.y);
-    return __builtin_bit_cast(b8v, v);
-}
-// split 4 floats into packed bf16 hi and lo parts
-__device__ __forceinline__ void split4(const float (&x)[4], uint2& hi, uint2& lo)
-{
-    hi.x = pack_bf2(x[0], x[1]);
-    hi.y = pack_bf2(x[2], x[3]);
-    lo.x = pack_bf2(x[0] - bf_lo(hi.x), x[1] - bf_hi(hi.x));
-    lo.y = pack_bf2(x[2] - bf_lo(hi.y), x[3] - bf_hi(hi.y));
-}
-
-template <bool W_RAW>
+// STATE_ONLY: no outputs, only the state recurrence; with a.ckpt the state at the entry of every 64-token
+// group is dumped (fp32, register order: [wave][tile][lane][4]) for the backward kernel.
+template <bool W_RAW, bool STATE_ONLY>
 __global__ __launch_bounds__(256) void chunk_fwd_kernel(const ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [NBLK][BLK_BYTES]
@@ -193,12 +151,14 @@ __global__ __launch_bounds__(256) void chunk_fwd_kernel(const ScanArgs a)
             }
             char* const row = bb + (4 * tq + tt) * RSB + 8 * c4;
             uint2 hi, lo;
-            split4(rh, hi, lo);
-            *reinterpret_cast<uint2*>(row + A_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_RL * ARR) = lo;
-            split4(kh, hi, lo);
-            *reinterpret_cast<uint2*>(row + A_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_KL * ARR) = lo;
-            split4(rz, hi, lo);
-            *reinterpret_cast<uint2*>(row + A_ZRH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_ZRL * ARR) = lo;
+            if constexpr (!STATE_ONLY) {
+                split4(rh, hi, lo);
+                *reinterpret_cast<uint2*>(row + A_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_RL * ARR) = lo;
+                split4(kh, hi, lo);
+                *reinterpret_cast<uint2*>(row + A_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_KL * ARR) = lo;
+                split4(rz, hi, lo);
+                *reinterpret_cast<uint2*>(row + A_ZRH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_ZRL * ARR) = lo;
+            }
             split4(kz, hi, lo);
             *reinterpret_cast<uint2*>(row + A_ZKH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_ZKL * ARR) = lo;
         }
@@ -210,9 +170,20 @@ __global__ __launch_bounds__(256) void chunk_fwd_kernel(const ScanArgs a)
         prep_group(grp);
         __syncthreads();
         if (grp + 1 < ngrp) load_group(grp + 1);                         // lands underneath phase C
+        if (a.ckpt) {
+            float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + GRP - 1) / GRP) + grp) * (HEAD * HEAD);
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                *reinterpret_cast<float4*>(ck + ((wv * 4 + it) * 64 + lane) * 4) =
+                    make_float4(St[it][0], St[it][1], St[it][2], St[it][3]);
+        }
         const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
         for (int blk = 0; blk < nb; ++blk) {
             const char* const bb = smem + blk * BLK_BYTES;
+            const int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
+            // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
+            const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);
+            if constexpr (!STATE_ONLY) {
             // (1) transposed scores  sc[b][a] = sum_i Khat[b][i] Rhat[a][i]; lane: column a = x, rows b = 4g + q
             f4v sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -234,9 +205,6 @@ __global__ __launch_bounds__(256) void chunk_fwd_kernel(const ScanArgs a)
             uint2 sh, sl;
             split4(scm, sh, sl);
             const s4v sc_hi = __builtin_bit_cast(s4v, sh), sc_lo = __builtin_bit_cast(s4v, sl);
-            // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
-            const int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
-            const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);
             // (2) y^T[j][a] = sum_b V[b][j] sc[b][a]
             f4v yt = {0.f, 0.f, 0.f, 0.f};
             yt = mfma16(vf, sc_hi, yt);
@@ -275,6 +243,7 @@ __global__ __launch_bounds__(256) void chunk_fwd_kernel(const ScanArgs a)
                     else io4<bf16_t>::store(gy_ + idx, o);
                 }
             }
+            }   // !STATE_ONLY
             // (4) S[it] <- e^{c16} (.) S[it] + Kz^T V
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -304,25 +273,36 @@ __global__ __launch_bounds__(256) void chunk_fwd_kernel(const ScanArgs a)
     }
 }
 
+template <bool W_RAW, bool STATE_ONLY> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)NBLK * BLK_BYTES;
+    static bool configured = false;            // per instantiation; the attribute is per function, set once
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY>), dim3(a.B * a.H), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)NBLK * BLK_BYTES;
-    const dim3 grid(a.B * a.H), block(256);
-    hipError_t e;
-    if (a.wkind) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_fwd_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(chunk_fwd_kernel<true>, grid, block, lds, st, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_fwd_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(chunk_fwd_kernel<false>, grid, block, lds, st, a);
-    }
-    return hipGetLastError();
+    return a.wkind ? launch_fwd_variant<true, false>(a, st) : launch_fwd_variant<false, false>(a, st);
+}
+
+// state recurrence only, dumping the group-entry states into a.ckpt (first half of the chunked backward)
+hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st)
+{
+    return a.wkind ? launch_fwd_variant<true, true>(a, st) : launch_fwd_variant<false, true>(a, st);
+}
+
+size_t chunk_ckpt_floats(int B, int T, int H)
+{
+    return (size_t)B * H * ((T + GRP - 1) / GRP) * HEAD * HEAD;
 }
 
 }  // namespace wkv6

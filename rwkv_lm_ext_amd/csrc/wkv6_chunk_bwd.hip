@@ -1,0 +1,479 @@
+// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O).  Companion of wkv6_chunk.hip; same block algebra.
+//
+// Per 16-token block (a = query token, b = key token, c_a exclusive cumulative log decay, S = forward state at
+// block entry, G = dL/d(state after the block)), with Rhat_a = r_a e^{c_a - c_8}, Khat_b = k_b e^{c_8 - c_{b+1}},
+// fR_a = e^{c_a - c_8}, fK_b = e^{c_8 - c_{b+1}}, E8 = e^{c_8}, E16 = e^{c_16}, E16m8 = e^{c_16 - c_8}:
+//   dA[a][b]  = gy_a . v_b                         (b < a),      vg_a = gy_a . v_a
+//   gv_b      = sum_{a>b} A[a][b] gy_a + (sum_i r_b u k_b) gy_b + sum_i Khat_b[i] (E16m8 (.) G)[i][:]
+//   dq_a      = fR_a (.) ( sum_{b<a} dA[a][b] Khat_b + (E8 (.) S) gy_a )        gr_a = dq_a + vg_a u (.) k_a
+//   dk_b      = fK_b (.) ( sum_{a>b} dA[a][b] Rhat_a + (E16m8 (.) G) v_b )      gk_b = dk_b + vg_b u (.) r_b
+//   G_entry   = E16 (.) G + E8 (.) sum_a Rhat_a gy_a^T
+//   gw_t      = lw_t (.) ( sum_{s>t} (r_s (.) dq_s - k_s (.) dk_s) - k_t (.) dk_t )   (suffix sum over the whole
+//               sequence; identity of fla/ops/rwkv6/recurrent_fuse.py:394-396, same as the scan kernels)
+//   gu       += vg_a r_a (.) k_a
+// i.e. the adjoint of cuda/wkv6_cuda.cu:44-57 (reference backward: cuda/wkv6_cuda.cu:63-227), re-associated.
+//
+// The forward states are needed in reverse order: a state-only pass of the forward kernel
+// (launch_chunk_state_pass) dumps the state at the entry of every 64-token group (fp32) into the workspace; this
+// kernel walks the groups backwards, rebuilds the three intermediate block states of a group in registers and
+// then processes its four blocks in reverse.
+//
+// One 256-thread workgroup per (batch, head).  Wave w owns key rows [16w,16w+16) for gr/gk/gw (state tiles held
+// transposed: lane = key row) and value columns [16w,16w+16) for gv; G is kept in both orientations because gk
+// contracts it over j and gv over i.
+#include "wkv6_chunk.h"
+
+namespace wkv6 {
+hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);
+
+namespace {
+
+using namespace chunk;
+
+enum { B_RH = 0, B_RL, B_KH, B_KL, B_V, B_GY, B_R, B_K, NB_ARR };      // bf16 [16][72] each
+constexpr int FRS = 68 * 4;                                            // bytes per fp32 token row (64 + 4 pad)
+constexpr int BOFF_CEX = NB_ARR * ARR;                                 // float [16][68]  c_a (exclusive)
+constexpr int BOFF_LW = BOFF_CEX + BLK * FRS;                          // float [16][68]  lw_a (unclamped)
+constexpr int BOFF_C8 = BOFF_LW + BLK * FRS;                           // float [64]
+constexpr int BOFF_E8 = BOFF_C8 + 256;
+constexpr int BOFF_E16 = BOFF_E8 + 256;
+constexpr int BOFF_E16M8 = BOFF_E16 + 256;
+constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float [16]  sum_i r u k
+constexpr int BBLK_BYTES = BOFF_COEF + 64;                             // 28224
+
+constexpr int DPP_SHL1 = 0x101, DPP_SHL2 = 0x102, DPP_SHL4 = 0x104, DPP_SHL8 = 0x108;   // row_shl:n, zero fill
+
+__device__ __forceinline__ float pick4(const f4v& v, int s)
+{
+    float o = v[0];
+    o = s == 1 ? v[1] : o;
+    o = s == 2 ? v[2] : o;
+    o = s == 3 ? v[3] : o;
+    return o;
+}
+// split a C-layout tile pair (8 floats) into the hi / lo bf16x8 fragments of one k-step
+__device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4], b8v& hi, b8v& lo)
+{
+    uint2 h0, l0, h1, l1;
+    split4(t0, h0, l0);
+    split4(t1, h1, l1);
+    hi = __builtin_bit_cast(b8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+
+template <bool W_RAW>
+__global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [NBLK][BBLK_BYTES]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r);
+    const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k);
+    const bf16_t* const gv_ = reinterpret_cast<const bf16_t*>(a.v);
+    const bf16_t* const ggy = reinterpret_cast<const bf16_t*>(a.gy);
+    bf16_t* const ogr = reinterpret_cast<bf16_t*>(a.gr);
+    bf16_t* const ogk = reinterpret_cast<bf16_t*>(a.gk);
+    bf16_t* const ogv = reinterpret_cast<bf16_t*>(a.gv);
+    bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw);
+    int ntok = a.T;
+    if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
+    const long base = (long)b * a.T * a.C + (long)h * HEAD;
+    const int ngmax = (a.T + GRP - 1) / GRP;
+
+    const int c4 = lane & 15, tq = lane >> 4;            // phase-P role
+    const int x = lane & 15, g = lane >> 4;              // phase-C role
+    float uu[4] = {0.f, 0.f, 0.f, 0.f}, ue[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.use_u) {
+        io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 4 * c4, uu);
+        io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
+    }
+
+    // ST[blk][jt][q] = S_entry(blk)[i = 16wv + x][j = 16jt + 4g + q]      (transposed tiles: lane = key row)
+    // GI[jt][q]      = G[i = 16wv + x][j = 16jt + 4g + q]
+    // GJ[it][q]      = G[i = 16it + 4g + q][j = 16wv + x]
+    f4v ST[4][4], GI[4], GJ[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { GI[t] = f4v{0.f, 0.f, 0.f, 0.f}; GJ[t] = f4v{0.f, 0.f, 0.f, 0.f}; }
+    float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
+
+    uint2 pr[4], pk[4], pv[4], pg[4], pw[4];
+    float4 pe[4];
+    auto load_group = [&](int grp) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int p = grp * GRP + wv * BLK + 4 * tq + tt;
+            pr[tt] = pk[tt] = pv[tt] = pg[tt] = pw[tt] = make_uint2(0u, 0u);
+            pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < ntok) {
+                const int t = a.reverse ? ntok - 1 - p : p;
+                const long idx = base + (long)t * a.C + 4 * c4;
+                pr[tt] = *reinterpret_cast<const uint2*>(gr_ + idx);
+                pk[tt] = *reinterpret_cast<const uint2*>(gk_ + idx);
+                pv[tt] = *reinterpret_cast<const uint2*>(gv_ + idx);
+                pg[tt] = *reinterpret_cast<const uint2*>(ggy + idx);
+                if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + idx);
+                else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + idx);
+            }
+        }
+    };
+
+    auto prep_group = [&](int grp) {
+        char* const bb = smem + wv * BBLK_BYTES;
+        float r[4][4], k[4][4], cs[4][4], lws[4][4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const bool valid = grp * GRP + wv * BLK + 4 * tq + tt < ntok;
+            r[tt][0] = bf_lo(pr[tt].x); r[tt][1] = bf_hi(pr[tt].x); r[tt][2] = bf_lo(pr[tt].y); r[tt][3] = bf_hi(pr[tt].y);
+            k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
+            float lw[4];
+            if constexpr (W_RAW) {
+                lw[0] = -__expf(bf_lo(pw[tt].x)); lw[1] = -__expf(bf_hi(pw[tt].x));
+                lw[2] = -__expf(bf_lo(pw[tt].y)); lw[3] = -__expf(bf_hi(pw[tt].y));
+            } else {
+                lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                lws[tt][c] = valid ? lw[c] : 0.f;                         // true log decay (for gw)
+                cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + fmaxf(lws[tt][c], LW_MIN);
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part = fmaf(r[tt][c] * uu[c], k[tt][c], part);
+            part = row_sum16(part);
+            char* const row = bb + (4 * tq + tt) * RSB + 8 * c4;
+            if (c4 == 0) *reinterpret_cast<float*>(bb + BOFF_COEF + (4 * tq + tt) * 4) = part;
+            *reinterpret_cast<uint2*>(row + B_V * ARR) = pv[tt];
+            *reinterpret_cast<uint2*>(row + B_GY * ARR) = pg[tt];
+            *reinterpret_cast<uint2*>(row + B_R * ARR) = pr[tt];
+            *reinterpret_cast<uint2*>(row + B_K * ARR) = pk[tt];
+            *reinterpret_cast<float4*>(bb + BOFF_LW + (4 * tq + tt) * FRS + 16 * c4) =
+                make_float4(lws[tt][0], lws[tt][1], lws[tt][2], lws[tt][3]);
+        }
+        float pre[4], c8[4], c16[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float inc = cs[3][c];
+            float t = __shfl_up(inc, 16);
+            if (tq >= 1) inc += t;
+            t = __shfl_up(inc, 32);
+            if (tq >= 2) inc += t;
+            pre[c] = inc - cs[3][c];
+            c8[c] = __shfl(pre[c], 32 + c4);
+            c16[c] = __shfl(inc, 48 + c4);
+        }
+        if (tq == 0) {
+            *reinterpret_cast<float4*>(bb + BOFF_C8 + 16 * c4) = make_float4(c8[0], c8[1], c8[2], c8[3]);
+            *reinterpret_cast<float4*>(bb + BOFF_E8 + 16 * c4) =
+                make_float4(__expf(c8[0]), __expf(c8[1]), __expf(c8[2]), __expf(c8[3]));
+            *reinterpret_cast<float4*>(bb + BOFF_E16 + 16 * c4) =
+                make_float4(__expf(c16[0]), __expf(c16[1]), __expf(c16[2]), __expf(c16[3]));
+            *reinterpret_cast<float4*>(bb + BOFF_E16M8 + 16 * c4) =
+                make_float4(__expf(c16[0] - c8[0]), __expf(c16[1] - c8[1]), __expf(c16[2] - c8[2]), __expf(c16[3] - c8[3]));
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            float rh[4], kh[4], cex[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                cex[c] = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
+                const float cin = pre[c] + cs[tt][c];
+                rh[c] = r[tt][c] * __expf(cex[c] - c8[c]);
+                kh[c] = k[tt][c] * __expf(c8[c] - cin);
+            }
+            char* const row = bb + (4 * tq + tt) * RSB + 8 * c4;
+            uint2 hi, lo;
+            split4(rh, hi, lo);
+            *reinterpret_cast<uint2*>(row + B_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + B_RL * ARR) = lo;
+            split4(kh, hi, lo);
+            *reinterpret_cast<uint2*>(row + B_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + B_KL * ARR) = lo;
+            *reinterpret_cast<float4*>(bb + BOFF_CEX + (4 * tq + tt) * FRS + 16 * c4) =
+                make_float4(cex[0], cex[1], cex[2], cex[3]);
+        }
+    };
+
+    const int ngrp = (ntok + GRP - 1) / GRP;
+    if (ngrp > 0) load_group(ngrp - 1);
+    for (int grp = ngrp - 1; grp >= 0; --grp) {
+        {   // group-entry forward state from the state pass (dumped in the forward kernel's register order)
+            const float* const ck = a.ckpt + ((long)blockIdx.x * ngmax + grp) * (HEAD * HEAD);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                float t4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    t4[q] = ck[((jt * 4 + wv) * 64 + 16 * (x >> 2) + 4 * g + q) * 4 + (x & 3)];
+                ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
+            }
+        }
+        prep_group(grp);
+        __syncthreads();
+        if (grp > 0) load_group(grp - 1);
+        const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
+        const int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
+
+        // ---- rebuild the entry states of blocks 1..3:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
+#pragma unroll
+        for (int blk = 0; blk < NBLK - 1; ++blk) {
+            if (blk + 1 < nb) {
+                const char* const bb = smem + blk * BBLK_BYTES;
+                const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
+                const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
+                const float e16 = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
+                const float e16m8 = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const s4v vf = tr_read(bb + B_V * ARR + troff + 32 * jt);
+                    f4v o = {0.f, 0.f, 0.f, 0.f};
+                    o = mfma16(vf, khf, o);
+                    o = mfma16(vf, klf, o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ST[blk + 1][jt][q] = fmaf(e16, ST[blk][jt][q], e16m8 * o[q]);
+                }
+            }
+        }
+
+        // ---- the four blocks in reverse
+#pragma unroll
+        for (int blk = NBLK - 1; blk >= 0; --blk) {
+            if (blk < nb) {
+                const char* const bb = smem + blk * BBLK_BYTES;
+                // dA in both orientations (exact bf16 operands) and the scores A[a][b]
+                f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int off = x * RSB + (32 * s + 8 * g) * 2;
+                    const b8v gyr = ld_b8(bb + B_GY * ARR + off), vr = ld_b8(bb + B_V * ARR + off);
+                    dA_ab = mfma32(gyr, vr, dA_ab);              // [row a][col b]: lane col b = x, rows a = 4g+q
+                    dA_ba = mfma32(vr, gyr, dA_ba);              // [row b][col a]: lane col a = x, rows b = 4g+q
+                    const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
+                    const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
+                    sc = mfma32(rh, kh, sc);                     // [row a][col b]
+                    sc = mfma32(rh, kl, sc);
+                    sc = mfma32(rl, kh, sc);
+                }
+                // vg_x = dA[x][x]: held by lane (x, g = x>>2) in register x&3
+                const float vg = __shfl(pick4(dA_ba, x & 3), 16 * (x >> 2) + x);
+                const float4 cf4 = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 16 * g);
+                const float cfa[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
+                float scm[4], dab[4], dba[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 4 * g + q;                      // the "row" token of all three tiles
+                    scm[q] = x < o ? sc[q] : (x == o ? cfa[q] : 0.f);   // A[a = o][b = x], diagonal = bonus coefficient
+                    dab[q] = x < o ? dA_ab[q] : 0.f;              // dA[a = o][b = x], strictly lower
+                    dba[q] = o < x ? dA_ba[q] : 0.f;              // dA^T[b = o][a = x], strictly lower
+                }
+                uint2 th, tl;
+                split4(scm, th, tl);
+                const s4v sc_hi = __builtin_bit_cast(s4v, th), sc_lo = __builtin_bit_cast(s4v, tl);
+                split4(dab, th, tl);
+                const s4v dab_hi = __builtin_bit_cast(s4v, th), dab_lo = __builtin_bit_cast(s4v, tl);
+                split4(dba, th, tl);
+                const s4v dba_hi = __builtin_bit_cast(s4v, th), dba_lo = __builtin_bit_cast(s4v, tl);
+
+                // fragments reused below
+                s4v gyT[4], rhf[4], rlf[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    gyT[t] = tr_read(bb + B_GY * ARR + troff + 32 * t);   // gy[4g+e][16t + x]
+                    rhf[t] = tr_read(bb + B_RH * ARR + troff + 32 * t);   // Rhat[4g+e][16t + x]
+                    rlf[t] = tr_read(bb + B_RL * ARR + troff + 32 * t);
+                }
+                const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
+                const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
+                const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
+                const float e16x = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
+                const float e16m8x = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
+
+                // ---- gv for value columns [16wv, 16wv+16):  gv^T[j][b]
+                {
+                    f4v acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = mfma16(gyT[wv], sc_hi, acc);
+                    acc = mfma16(gyT[wv], sc_lo, acc);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float t0[4], t1[4];
+                        const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 4 * g) * 4);
+                        const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 16 + 4 * g) * 4);
+                        t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
+                        t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
+                        t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
+                        b8v gh, gl;
+                        split8(t0, t1, gh, gl);
+                        const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
+                        const b8v kh = ld_b8_2x4(p0 + B_KH * ARR, p0 + B_KH * ARR + 32);
+                        const b8v kl = ld_b8_2x4(p0 + B_KL * ARR, p0 + B_KL * ARR + 32);
+                        acc = mfma32(gh, kh, acc);
+                        acc = mfma32(gh, kl, acc);
+                        acc = mfma32(gl, kh, acc);
+                    }
+                    const int p = grp * GRP + blk * BLK + x;
+                    if (p < ntok) {
+                        const int t = a.reverse ? ntok - 1 - p : p;
+                        const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
+                        float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+                        if (a.accumulate) {
+                            float old[4];
+                            io4<bf16_t>::load(ogv + idx, old);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o[q] += old[q];
+                        }
+                        io4<bf16_t>::store(ogv + idx, o);
+                    }
+                }
+
+                // ---- gr / gk / gw for key rows [16wv, 16wv+16): accumulators [i_local = 4g+q][token x]
+                f4v accr = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float t0[4], t1[4];
+                    b8v hi, lo;
+                    const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q] * e8x; t1[q] = ST[blk][2 * s + 1][q] * e8x; }
+                    split8(t0, t1, hi, lo);
+                    const b8v gyp = ld_b8_2x4(p0 + B_GY * ARR, p0 + B_GY * ARR + 32);
+                    accr = mfma32(hi, gyp, accr);
+                    accr = mfma32(lo, gyp, accr);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
+                    split8(t0, t1, hi, lo);
+                    const b8v vp = ld_b8_2x4(p0 + B_V * ARR, p0 + B_V * ARR + 32);
+                    acck = mfma32(hi, vp, acck);
+                    acck = mfma32(lo, vp, acck);
+                }
+                accr = mfma16(khf, dba_hi, accr);                // sum_b Khat[b][i] dA[a][b]
+                accr = mfma16(khf, dba_lo, accr);
+                accr = mfma16(klf, dba_hi, accr);
+                acck = mfma16(rhf[wv], dab_hi, acck);            // sum_a Rhat[a][i] dA[a][b]
+                acck = mfma16(rhf[wv], dab_lo, acck);
+                acck = mfma16(rlf[wv], dab_hi, acck);
+                {
+                    const int ch = 16 * wv + 4 * g;
+                    const float4 cex4 = *reinterpret_cast<const float4*>(bb + BOFF_CEX + x * FRS + ch * 4);
+                    const float4 lw4 = *reinterpret_cast<const float4*>(bb + BOFF_LW + x * FRS + ch * 4);
+                    const float4 c84 = *reinterpret_cast<const float4*>(bb + BOFF_C8 + ch * 4);
+                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
+                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
+                    const float cexv[4] = {cex4.x, cex4.y, cex4.z, cex4.w}, lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
+                    const float c8v[4] = {c84.x, c84.y, c84.z, c84.w};
+                    const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                    const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
+                    float o_gr[4], o_gk[4], o_gw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lwc = fmaxf(lwv[q], LW_MIN);              // the decay the block algebra used
+                        const float dq = __expf(cexv[q] - c8v[q]) * accr[q];
+                        const float dk = __expf(c8v[q] - cexv[q] - lwc) * acck[q];
+                        o_gr[q] = fmaf(vg * ue[q], kv[q], dq);
+                        o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
+                        gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
+                        const float bt = kv[q] * dk;
+                        const float dl = rv[q] * dq - bt;
+                        float sfx = dl;                           // inclusive suffix sum over the later tokens of the row
+                        sfx += dpp_mov<DPP_SHL1>(sfx);
+                        sfx += dpp_mov<DPP_SHL2>(sfx);
+                        sfx += dpp_mov<DPP_SHL4>(sfx);
+                        sfx += dpp_mov<DPP_SHL8>(sfx);
+                        const float total = __shfl(sfx, lane & 48);
+                        // d(loss)/d(ew) of the clamped model is d_clamped * X; the true one is d_true * X, so where the
+                        // clamp is active rescale by d_true / d_clamped = e^{lw - lwc} (exactly 1 elsewhere)
+                        o_gw[q] = (Rc[q] + (sfx - dl) - bt) * lwv[q] * __expf(lwv[q] - lwc);
+                        Rc[q] += total;
+                    }
+                    const int p = grp * GRP + blk * BLK + x;
+                    if (p < ntok) {
+                        const int t = a.reverse ? ntok - 1 - p : p;
+                        const long idx = base + (long)t * a.C + ch;
+                        if (a.accumulate) {
+                            float o1[4], o2[4], o3[4];
+                            io4<bf16_t>::load(ogr + idx, o1);
+                            io4<bf16_t>::load(ogk + idx, o2);
+                            io4<bf16_t>::load(ogw + idx, o3);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { o_gr[q] += o1[q]; o_gk[q] += o2[q]; o_gw[q] += o3[q]; }
+                        }
+                        io4<bf16_t>::store(ogr + idx, o_gr);
+                        io4<bf16_t>::store(ogk + idx, o_gk);
+                        io4<bf16_t>::store(ogw + idx, o_gw);
+                    }
+                }
+
+                // ---- G <- E16 (.) G + E8 (.) (Rhat^T gy), in both orientations
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    f4v o = {0.f, 0.f, 0.f, 0.f};
+                    o = mfma16(gyT[jt], rhf[wv], o);             // [row j_local][col i_local = x]
+                    o = mfma16(gyT[jt], rlf[wv], o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * o[q]);
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    f4v o = {0.f, 0.f, 0.f, 0.f};
+                    o = mfma16(rhf[it], gyT[wv], o);             // [row i_local][col j_local = x]
+                    o = mfma16(rlf[it], gyT[wv], o);
+                    const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (16 * it + 4 * g) * 4);
+                    const float4 d8 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (16 * it + 4 * g) * 4);
+                    GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * o[0]);
+                    GJ[it][1] = fmaf(d16.y, GJ[it][1], d8.y * o[1]);
+                    GJ[it][2] = fmaf(d16.z, GJ[it][2], d8.z * o[2]);
+                    GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * o[3]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (a.gs) {   // dL/dS0, layout [j][i]
+        bf16_t* const og = reinterpret_cast<bf16_t*>(a.gs) + ((long)b * a.H + h) * HEAD * HEAD;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float t4[4] = {GJ[it][0], GJ[it][1], GJ[it][2], GJ[it][3]};
+            io4<bf16_t>::store(og + (long)(16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
+        }
+    }
+    if (a.gu) {
+        float s4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s4[q] = row_sum16(gu_acc[q]);
+        if (x == 0) io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.gu) + (long)b * a.C + h * HEAD + 16 * wv + 4 * g, s4);
+    }
+    if (a.zero_tail && !a.accumulate) {
+        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = ntok + (tid >> 4); t < a.T; t += 16) {
+            const long idx = base + (long)t * a.C + 4 * c4;
+            io4<bf16_t>::store(ogr + idx, z);
+            io4<bf16_t>::store(ogk + idx, z);
+            io4<bf16_t>::store(ogv + idx, z);
+            io4<bf16_t>::store(ogw + idx, z);
+        }
+    }
+}
+
+template <bool W_RAW> hipError_t launch_bwd_variant(const ScanArgs& a, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)NBLK * BBLK_BYTES;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_bwd_kernel<W_RAW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((chunk_bwd_kernel<W_RAW>), dim3(a.B * a.H), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
+{
+    ScanArgs sp = a;                       // state pass: same inputs, no outputs, dump group-entry states
+    sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
+    if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
+    return a.wkind ? launch_bwd_variant<true>(a, st) : launch_bwd_variant<false>(a, st);
+}
+
+}  // namespace wkv6

@@ -37,6 +37,7 @@ struct ScanArgs {
     void* gu;                         // [B,C] per-batch partials, I/O type (null: skip)
     void* gs;                         // [B,H,N,N] per-batch dL/dS0, I/O type (null: skip)
     float* aux;                       // [B,T,C] fp32 scratch carrying a_t from sweep S to sweep G
+    float* ckpt;                      // chunked path: [B*H][ceil(T/64)][4096] fp32 group-entry states (state pass -> backward)
     const int* lens;                  // per-batch number of tokens to scan (null: T)
     int reverse;                      // 1: scan tokens lens-1 .. 0
     int use_u;                        // 0: bonus u treated as 0 (reverse half of wkv6_bi)
@@ -49,5 +50,8 @@ hipError_t launch_scan_bwd(const ScanArgs& a, bool io_f32, hipStream_t st);
 hipError_t launch_selftest(int* result, hipStream_t st);
 // chunked MFMA forward (bf16 I/O only), wkv6_chunk.hip
 hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st);
+// chunked MFMA backward (bf16 I/O only): state pass + reverse pass; a.ckpt must hold chunk_ckpt_floats() floats
+hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st);
+size_t chunk_ckpt_floats(int B, int T, int H);
 
 }  // namespace wkv6

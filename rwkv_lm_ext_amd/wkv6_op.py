@@ -189,7 +189,7 @@ def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None, alg
     return y
 
 
-def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False):
+def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False, algo=None):
     """Returns (gr, gk, gv, gw, gu[B,C], gs[B,H,N,N] or None) in the I/O type of `r`."""
     B, T, C = r.shape
     io = r.dtype
@@ -198,6 +198,7 @@ def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False):
     named = dict(r=(r, btc, io), k=(k, btc, io), v=(v, btc, io), w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io),
                  gy=(gy, btc, io))
     flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
+    flags |= _lib.ALGO_SCAN if algo == "scan" else 0
     if s0 is not None:
         per_batch = s0.dim() == 4
         named["s0"] = (s0, (B, H, HEAD_SIZE, HEAD_SIZE) if per_batch else (H, HEAD_SIZE, HEAD_SIZE), io)
@@ -234,7 +235,7 @@ def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None):
     return y
 
 
-def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False):
+def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False, algo=None):
     B, T, C = r.shape
     io = r.dtype
     btc = (B, T, C)
@@ -242,6 +243,7 @@ def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False):
     named = dict(mask=(mask, (B, T), torch.int32), r=(r, btc, io), k=(k, btc, io), v=(v, btc, io),
                  w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io), gy=(gy, btc, io))
     flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
+    flags |= _lib.ALGO_SCAN if algo == "scan" else 0
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
     gu = torch.empty((B, C), device=dev, dtype=io)

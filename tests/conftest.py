@@ -36,7 +36,7 @@ def bf16_round(x):
     return r.astype(np.uint32).view(np.float32)
 
 
-def bf16_report(out, ref):
+def bf16_report(out, ref, floor=1e-3):
     """Compare a bf16 kernel output (as float32) with the fp64/fp32 oracle result.
 
     Returns (rel_rms, frac_off, max_ulps): error against RNE_bf16(oracle), normalised by the rms of the
@@ -47,9 +47,9 @@ def bf16_report(out, ref):
     ref = np.asarray(ref, np.float64)
     want = bf16_round(ref.astype(np.float32)).astype(np.float64)
     d = out - want
-    rms = max(np.sqrt(np.mean(ref ** 2)), 1e-3)
+    rms = max(np.sqrt(np.mean(ref ** 2)), floor)
     rel_rms = float(np.sqrt(np.mean(d ** 2)) / rms)
-    floor = max(1e-2 * np.abs(ref).max(), 1e-3)
+    floor = max(1e-2 * np.abs(ref).max(), floor)
     big = np.abs(ref) >= floor            # elements below 1 % of the tensor scale sit in fp32 noise
     frac_off = float(np.mean(d[big] != 0)) if big.any() else 0.0
     ulp = np.maximum(np.abs(ref), floor) * 2.0 ** -7
