@@ -280,6 +280,10 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
                     rhf[t] = tr_read(bb + B_RH * ARR + troff + 32 * t);   // Rhat[4g+e][16t + x]
                     rlf[t] = tr_read(bb + B_RL * ARR + troff + 32 * t);
                 }
+                // this wave's own tiles, read by address (indexing gyT[wv] would be a runtime register index)
+                const s4v gyT_w = tr_read(bb + B_GY * ARR + troff + 32 * wv);
+                const s4v rhf_w = tr_read(bb + B_RH * ARR + troff + 32 * wv);
+                const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
                 const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
                 const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
                 const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
@@ -289,8 +293,8 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
                 // ---- gv for value columns [16wv, 16wv+16):  gv^T[j][b]
                 {
                     f4v acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = mfma16(gyT[wv], sc_hi, acc);
-                    acc = mfma16(gyT[wv], sc_lo, acc);
+                    acc = mfma16(gyT_w, sc_hi, acc);
+                    acc = mfma16(gyT_w, sc_lo, acc);
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         float t0[4], t1[4];
@@ -346,9 +350,9 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
                 accr = mfma16(khf, dba_hi, accr);                // sum_b Khat[b][i] dA[a][b]
                 accr = mfma16(khf, dba_lo, accr);
                 accr = mfma16(klf, dba_hi, accr);
-                acck = mfma16(rhf[wv], dab_hi, acck);            // sum_a Rhat[a][i] dA[a][b]
-                acck = mfma16(rhf[wv], dab_lo, acck);
-                acck = mfma16(rlf[wv], dab_hi, acck);
+                acck = mfma16(rhf_w, dab_hi, acck);            // sum_a Rhat[a][i] dA[a][b]
+                acck = mfma16(rhf_w, dab_lo, acck);
+                acck = mfma16(rlf_w, dab_hi, acck);
                 {
                     const int ch = 16 * wv + 4 * g;
                     const float4 cex4 = *reinterpret_cast<const float4*>(bb + BOFF_CEX + x * FRS + ch * 4);
@@ -404,16 +408,16 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     f4v o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma16(gyT[jt], rhf[wv], o);             // [row j_local][col i_local = x]
-                    o = mfma16(gyT[jt], rlf[wv], o);
+                    o = mfma16(gyT[jt], rhf_w, o);             // [row j_local][col i_local = x]
+                    o = mfma16(gyT[jt], rlf_w, o);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * o[q]);
                 }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     f4v o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma16(rhf[it], gyT[wv], o);             // [row i_local][col j_local = x]
-                    o = mfma16(rlf[it], gyT[wv], o);
+                    o = mfma16(rhf[it], gyT_w, o);             // [row i_local][col j_local = x]
+                    o = mfma16(rlf[it], gyT_w, o);
                     const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (16 * it + 4 * g) * 4);
                     const float4 d8 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (16 * it + 4 * g) * 4);
                     GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * o[0]);
