@@ -104,12 +104,13 @@ def main():
 
     if args.workload == "wkv6":
         y = torch.empty_like(r)
+        ckpt = wkv6_op.new_checkpoint(B, T, C, H, dev)     # forward-state checkpoints, as WKV_6.apply keeps them
 
         def fwd():
-            wkv6_op.forward_ex(r, k, v, w, u, H, y=y)
+            wkv6_op.forward_ex(r, k, v, w, u, H, y=y, ckpt=ckpt)
 
         def bwd():
-            wkv6_op.backward_ex(r, k, v, w, u, gy, H)
+            wkv6_op.backward_ex(r, k, v, w, u, gy, H, ckpt=ckpt)
     elif args.workload == "infctx":
         chunks = [slice(2048 * c, 2048 * (c + 1)) for c in range(8)]
         parts = [[x[:, sl].contiguous() for x in (r, k, v, w, gy)] for sl in chunks]

@@ -74,7 +74,9 @@ enum {
     WKV6_W_RAW = 1,         /* w is the raw decay in the I/O type               */
     WKV6_IO_F32 = 2,        /* every bf16 tensor is fp32 instead (numerics tests) */
     WKV6_S0_PER_BATCH = 4,  /* s0 is [B,H,N,N] (infctx) instead of [H,N,N] (state) */
-    WKV6_ALGO_SCAN = 16     /* force the exact token-serial kernels            */
+    WKV6_ALGO_SCAN = 16,    /* force the exact token-serial kernels            */
+    WKV6_CKPT_VALID = 32    /* backward: `workspace` already holds the checkpoints written by wkv6_forward_ckpt_ex
+                               for the same inputs, so the backward skips its own state pass */
 };
 /* Bytes of scratch the backward needs (the forward needs none). */
 size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H);
@@ -83,6 +85,13 @@ size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H);
 int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                     const void* w, const void* u, const void* s0, void* s_out, void* y,
                     unsigned flags, void* stream);
+/* Same as wkv6_forward_ex, and additionally stores the forward state at the entry of every 64-token group
+ * (fp32, wkv6_backward_workspace_bytes() bytes) into `ckpt` -- the activation checkpoint a following
+ * wkv6_backward_ex(..., workspace = ckpt, flags | WKV6_CKPT_VALID) consumes.  bf16 I/O, chunked kernels only;
+ * returns WKV6_EUNSUPPORTED for WKV6_IO_F32 / WKV6_ALGO_SCAN. */
+int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                         const void* w, const void* u, const void* s0, void* s_out, void* y,
+                         void* ckpt, size_t ckpt_bytes, unsigned flags, void* stream);
 /* gu, gs may be NULL (skipped).  workspace: wkv6_backward_workspace_bytes() bytes, or NULL to use a
  * library-owned grow-only buffer (not safe for concurrent use from several streams). */
 int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,

@@ -27,6 +27,7 @@ SIGNATURES = {
     "wkv6_backward_workspace_bytes": (_SZ, [_I] * 4),
     "wkv6bi_workspace_bytes": (_SZ, [_I] * 4),
     "wkv6_forward_ex": (_I, [_I] * 4 + [_VP] * 8 + [_U, _VP]),
+    "wkv6_forward_ckpt_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ, _U, _VP]),
     "wkv6_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
     "wkv6bi_forward_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ, _U, _VP]),
     "wkv6bi_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
@@ -35,7 +36,7 @@ SIGNATURES = {
 }
 
 # flags of include/wkv6_amd.h
-W_EW_F32, W_RAW, IO_F32, S0_PER_BATCH, ALGO_SCAN = 0, 1, 2, 4, 16
+W_EW_F32, W_RAW, IO_F32, S0_PER_BATCH, ALGO_SCAN, CKPT_VALID = 0, 1, 2, 4, 16, 32
 
 ERRORS = {-1: "WKV6_EINVAL (shape: need C == H*64 and B,T,C,H >= 1)", -2: "WKV6_ENULL (null pointer)",
           -3: "WKV6_EWORKSPACE (workspace too small / allocation failed)", -4: "WKV6_EUNSUPPORTED"}

@@ -81,6 +81,7 @@ hipError_t run_bwd(ScanArgs& a, unsigned flags, float* scratch, hipStream_t st)
         return launch_scan_bwd(a, flags & WKV6_IO_F32, st);
     }
     a.ckpt = scratch;
+    a.ckpt_valid = (flags & WKV6_CKPT_VALID) ? 1 : 0;
     return launch_chunk_bwd(a, st);
 }
 
@@ -125,6 +126,23 @@ int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, co
     a.s_out = s_out;
     a.y = y;
     return to_rc(run_fwd(a, flags, (hipStream_t)stream));
+}
+
+int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
+                         const void* w, const void* u, const void* s0, void* s_out, void* y,
+                         void* ckpt, size_t ckpt_bytes, unsigned flags, void* stream)
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!r || !k || !v || !w || !u || !y || !ckpt) return WKV6_ENULL;
+    if (flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) return WKV6_EUNSUPPORTED;
+    if (ckpt_bytes < wkv6_backward_workspace_bytes(B, T, C, H)) return WKV6_EWORKSPACE;
+    ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
+    a.s0 = s0;
+    a.s0_bstride = (flags & WKV6_S0_PER_BATCH) ? (long)H * HEAD * HEAD : 0;
+    a.s_out = s_out;
+    a.y = y;
+    a.ckpt = reinterpret_cast<float*>(ckpt);
+    return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
 }
 
 int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,

@@ -14,10 +14,12 @@ constexpr int NBLK = 4;                       // blocks per group (= waves)
 constexpr int GRP = BLK * NBLK;               // 64 tokens per group
 constexpr int RSB = 144;                      // bytes per staged token row (64 bf16 + 8 pad): conflict-free b128 reads
 constexpr int ARR = BLK * RSB;                // one operand array
-enum { A_RH = 0, A_RL, A_KH, A_KL, A_ZRH, A_ZRL, A_ZKH, A_ZKL, A_V, N_ARR };
-constexpr int OFF_D = N_ARR * ARR;            // float[64]  e^{c_16}
-constexpr int OFF_COEF = OFF_D + 64 * 4;      // float[16]  sum_i r u k
-constexpr int BLK_BYTES = OFF_COEF + 16 * 4;  // 21056
+enum { A_RH = 0, A_RL, A_KH, A_KL, A_V, N_ARR };       // forward operand arrays, bf16 [16][72] each
+constexpr int OFF_E8 = N_ARR * ARR;                    // float[64]  e^{c_8}
+constexpr int OFF_E16 = OFF_E8 + 256;                  // float[64]  e^{c_16}
+constexpr int OFF_E16M8 = OFF_E16 + 256;               // float[64]  e^{c_16 - c_8}
+constexpr int OFF_COEF = OFF_E16M8 + 256;              // float[16]  sum_i r u k
+constexpr int BLK_BYTES = OFF_COEF + 16 * 4;           // 12352
 constexpr float LW_MIN = -9.0f;
 
 __device__ __forceinline__ s4v tr_read(const char* p)

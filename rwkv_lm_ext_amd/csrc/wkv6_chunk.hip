@@ -4,12 +4,12 @@
 // (DESIGN.md section 4).  Here the O(N^2)-per-token work runs on the matrix cores instead:
 //
 //   per 16-token block (a, b = token in block, i = key channel, j = value channel, c_a = exclusive
-//   cumulative log-decay inside the block, lw = -exp(w) clamped to >= LW_MIN):
-//     scores   A[a][b] = sum_i r_a[i] k_b[i] exp(c_a[i] - c_{b+1}[i])   (b < a),   A[a][a] = sum_i r_a u k_a
-//              = (r_a . e^{c_a - c_8}) (k_b . e^{c_8 - c_{b+1}})          one reference point (token 8) per block,
-//                                                                          so every exponent is within 8 tokens
-//     output   y_a = A[a][:] V  +  (r_a . e^{c_a})^T S                    S = state at block entry
-//     state    S  <- diag(e^{c_16}) S + (k_b . e^{c_16 - c_{b+1}})^T V
+//   cumulative log-decay inside the block, lw = -exp(w) clamped to >= LW_MIN), with
+//   Rhat_a = r_a . e^{c_a - c_8},  Khat_b = k_b . e^{c_8 - c_{b+1}}   (one reference point, token 8, per block,
+//   so every exponent spans at most 8 tokens),  E8 = e^{c_8},  E16 = e^{c_16},  E16m8 = e^{c_16 - c_8}:
+//     scores   A[a][b] = Rhat_a . Khat_b  (b < a),     A[a][a] = sum_i r_a u k_a
+//     output   y_a = A[a][:] V  +  Rhat_a^T (E8 (.) S)                     S = state at block entry
+//     state    S  <- E16 (.) S + E16m8 (.) (Khat^T V)
 //   which is the recurrence of cuda/wkv6_cuda.cu:44-57 re-associated (same algebra as the reference's own
 //   alternative backend, fla/ops/rwkv6/chunk.py:114-309, but with the state kept in registers for the whole
 //   sequence instead of being spilled per chunk, and with split-bf16 operands instead of bf16-rounded ones).
@@ -18,13 +18,16 @@
 //   is formed as hi*hi + hi*lo + lo*hi with fp32 accumulation, so results carry ~2^-16 relative error instead
 //   of bf16's 2^-8; r, k, v themselves are exact in bf16.
 //
-// Work split: one 256-thread workgroup (4 wave64) per (batch, head).  Tokens are processed in groups of 64:
-//   phase P: wave w turns block w of the group into MFMA operands in LDS (decays, cumulative sums, scaling,
-//            hi/lo split) -- lane = (4 channels, 4 tokens);
-//   phase C: every wave walks the 4 blocks; wave w owns value columns [16w, 16w+16) of the state, held as the
-//            C-layout of four 16x16 MFMA tiles (16 fp32 VGPRs), so the state-update MFMA accumulates in place
-//            and the same registers, converted to bf16, are the A operand of the inter-block product.
-//   The next group's global loads are issued before phase C and land underneath it.
+// Work split: one 512-thread workgroup (8 wave64) per (batch, head); tokens go through in groups of 64.
+//   producer waves 4..7: wave 4+w turns block w of group g+1 into MFMA operands in the other LDS buffer
+//            (decays, cumulative sums, scaling, hi/lo split; lane = 4 channels x 4 tokens) and issues the global
+//            loads of group g+2;
+//   consumer waves 0..3: walk the 4 blocks of group g; wave w owns value columns [16w, 16w+16) of the state as
+//            the C-layout of four 16x16 MFMA tiles (16 fp32 VGPRs): the state-update MFMA result lands in that
+//            layout and the same registers, scaled and converted to bf16, are the A operand of the
+//            inter-block product.
+//   One workgroup barrier per group; producers and consumers share each SIMD (2 waves per SIMD), so operand
+//   preparation (VALU/transcendental) overlaps the MFMA chain.
 //
 // Decays smaller than e^LW_MIN per token are clamped (their true effect on any output is < 1.3e-4 of the
 // carried state, far below bf16 output resolution); the exact scan kernels remain available (WKV6_ALGO_SCAN).
@@ -35,13 +38,19 @@ namespace {
 
 using namespace chunk;
 
-// STATE_ONLY: no outputs, only the state recurrence; with a.ckpt the state at the entry of every 64-token
-// group is dumped (fp32, register order: [wave][tile][lane][4]) for the backward kernel.
+constexpr int GRP_BYTES = NBLK * BLK_BYTES;
+
+// STATE_ONLY: no outputs, only the state recurrence (first half of the self-contained backward).
+// With a.ckpt the state at the entry of every 64-token group is dumped (fp32, register order:
+// [wave][tile][lane][4]) for the backward kernel.
 template <bool W_RAW, bool STATE_ONLY>
-__global__ __launch_bounds__(256) void chunk_fwd_kernel(const ScanArgs a)
+__global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [NBLK][BLK_BYTES]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform, provably so
+    const bool producer = wid >= 4;
+    const int wv = wid & 3;                                          // block (producer) / column tile (consumer)
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r);
     const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k);
@@ -50,232 +59,245 @@ __global__ __launch_bounds__(256) void chunk_fwd_kernel(const ScanArgs a)
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const long base = (long)b * a.T * a.C + (long)h * HEAD;
-
-    // ---- phase-P role: 4 channels x 4 tokens of block `wv`
-    const int c4 = lane & 15, tq = lane >> 4;
-    float uu[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 4 * c4, uu);
-
-    // ---- phase-C role: value columns [16wv, 16wv+16); lane (x = lane&15, g = lane>>4) holds
-    //      S[i = 16it + 4g + q][j = 16wv + x] in St[it][q]  (C layout of four 16x16 tiles)
-    const int x = lane & 15, g = lane >> 4;
-    f4v St[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        float t4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.s0)
-            io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.s0) + (long)b * a.s0_bstride +
-                              ((long)h * HEAD + 16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
-        St[it] = f4v{t4[0], t4[1], t4[2], t4[3]};
-    }
-
-    // prefetched raw inputs of the next group (4 tokens x 4 channels per lane)
-    uint2 pr[4], pk[4], pv[4], pw[4];
-    float4 pe[4];
-    auto load_group = [&](int grp) {
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int p = grp * GRP + wv * BLK + 4 * tq + tt;
-            pr[tt] = pk[tt] = pv[tt] = pw[tt] = make_uint2(0u, 0u);
-            pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < ntok) {
-                const int t = a.reverse ? ntok - 1 - p : p;
-                const long idx = base + (long)t * a.C + 4 * c4;
-                pr[tt] = *reinterpret_cast<const uint2*>(gr_ + idx);
-                pk[tt] = *reinterpret_cast<const uint2*>(gk_ + idx);
-                pv[tt] = *reinterpret_cast<const uint2*>(gv_ + idx);
-                if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + idx);
-                else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + idx);
-            }
-        }
-    };
-
-    auto prep_group = [&](int grp) {
-        char* const bb = smem + wv * BLK_BYTES;
-        float r[4][4], k[4][4], cs[4][4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const bool valid = grp * GRP + wv * BLK + 4 * tq + tt < ntok;
-            r[tt][0] = bf_lo(pr[tt].x); r[tt][1] = bf_hi(pr[tt].x); r[tt][2] = bf_lo(pr[tt].y); r[tt][3] = bf_hi(pr[tt].y);
-            k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
-            float lw[4];
-            if constexpr (W_RAW) {
-                lw[0] = -__expf(bf_lo(pw[tt].x)); lw[1] = -__expf(bf_hi(pw[tt].x));
-                lw[2] = -__expf(bf_lo(pw[tt].y)); lw[3] = -__expf(bf_hi(pw[tt].y));
-            } else {
-                lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float l = valid ? fmaxf(lw[c], LW_MIN) : 0.f;
-                cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + l;              // inclusive, within this lane's 4 tokens
-            }
-            // bonus coefficient of the diagonal: sum over the 64 channels = 4 in-lane x 16 lanes of the row
-            float part = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) part = fmaf(r[tt][c] * uu[c], k[tt][c], part);
-            part = row_sum16(part);
-            if (c4 == 0) *reinterpret_cast<float*>(bb + OFF_COEF + (4 * tq + tt) * 4) = part;
-            *reinterpret_cast<uint2*>(bb + A_V * ARR + (4 * tq + tt) * RSB + 8 * c4) = pv[tt];
-        }
-        float pre[4], c8[4], c16[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float inc = cs[3][c];
-            float t = __shfl_up(inc, 16);
-            if (tq >= 1) inc += t;
-            t = __shfl_up(inc, 32);
-            if (tq >= 2) inc += t;
-            pre[c] = inc - cs[3][c];                                     // decay accumulated before this lane's tokens
-            c8[c] = __shfl(pre[c], 32 + c4);                             // ... before token 8
-            c16[c] = __shfl(inc, 48 + c4);                               // whole block
-        }
-        float e8[4], e16[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { e8[c] = __expf(c8[c]); e16[c] = __expf(c16[c] - c8[c]); }
-        if (tq == 0) {
-            const float4 d = make_float4(__expf(c16[0]), __expf(c16[1]), __expf(c16[2]), __expf(c16[3]));
-            *reinterpret_cast<float4*>(bb + OFF_D + 16 * c4) = d;
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            float rh[4], kh[4], rz[4], kz[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float cex = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
-                const float cin = pre[c] + cs[tt][c];
-                rh[c] = r[tt][c] * __expf(cex - c8[c]);
-                kh[c] = k[tt][c] * __expf(c8[c] - cin);
-                rz[c] = rh[c] * e8[c];
-                kz[c] = kh[c] * e16[c];
-            }
-            char* const row = bb + (4 * tq + tt) * RSB + 8 * c4;
-            uint2 hi, lo;
-            if constexpr (!STATE_ONLY) {
-                split4(rh, hi, lo);
-                *reinterpret_cast<uint2*>(row + A_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_RL * ARR) = lo;
-                split4(kh, hi, lo);
-                *reinterpret_cast<uint2*>(row + A_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_KL * ARR) = lo;
-                split4(rz, hi, lo);
-                *reinterpret_cast<uint2*>(row + A_ZRH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_ZRL * ARR) = lo;
-            }
-            split4(kz, hi, lo);
-            *reinterpret_cast<uint2*>(row + A_ZKH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_ZKL * ARR) = lo;
-        }
-    };
-
     const int ngrp = (ntok + GRP - 1) / GRP;
-    if (ngrp > 0) load_group(0);
-    for (int grp = 0; grp < ngrp; ++grp) {
-        prep_group(grp);
-        __syncthreads();
-        if (grp + 1 < ngrp) load_group(grp + 1);                         // lands underneath phase C
-        if (a.ckpt) {
-            float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + GRP - 1) / GRP) + grp) * (HEAD * HEAD);
+
+    if (producer) {
+        // ================================ producer: operands of block wv =================================
+        const int c4 = lane & 15, tq = lane >> 4;                    // 4 channels x 4 tokens per lane
+        float uu[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 4 * c4, uu);
+        uint2 pr[4], pk[4], pv[4], pw[4];
+        float4 pe[4];
+        auto load_group = [&](int grp) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
-                *reinterpret_cast<float4*>(ck + ((wv * 4 + it) * 64 + lane) * 4) =
-                    make_float4(St[it][0], St[it][1], St[it][2], St[it][3]);
-        }
-        const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
-        for (int blk = 0; blk < nb; ++blk) {
-            const char* const bb = smem + blk * BLK_BYTES;
-            const int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
-            // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
-            const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);
-            if constexpr (!STATE_ONLY) {
-            // (1) transposed scores  sc[b][a] = sum_i Khat[b][i] Rhat[a][i]; lane: column a = x, rows b = 4g + q
-            f4v sc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int off = x * RSB + (32 * s + 8 * g) * 2;
-                const b8v kh = ld_b8(bb + A_KH * ARR + off), kl = ld_b8(bb + A_KL * ARR + off);
-                const b8v rh = ld_b8(bb + A_RH * ARR + off), rl = ld_b8(bb + A_RL * ARR + off);
-                sc = mfma32(kh, rh, sc);
-                sc = mfma32(kh, rl, sc);
-                sc = mfma32(kl, rh, sc);
-            }
-            const float cf = *reinterpret_cast<const float*>(bb + OFF_COEF + x * 4);
-            float scm[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int bt = 4 * g + q;                                // key token; query token = x
-                scm[q] = bt < x ? sc[q] : (bt == x ? cf : 0.f);
-            }
-            uint2 sh, sl;
-            split4(scm, sh, sl);
-            const s4v sc_hi = __builtin_bit_cast(s4v, sh), sc_lo = __builtin_bit_cast(s4v, sl);
-            // (2) y^T[j][a] = sum_b V[b][j] sc[b][a]
-            f4v yt = {0.f, 0.f, 0.f, 0.f};
-            yt = mfma16(vf, sc_hi, yt);
-            yt = mfma16(vf, sc_lo, yt);
-            // (3) y^T[j][a] += sum_i S[i][j] Rz[a][i]; k-slot (s, g, e) <-> channel 32s + 16(e>>2) + 4g + (e&3)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const float sv[2][4] = {{St[2 * s][0], St[2 * s][1], St[2 * s][2], St[2 * s][3]},
-                                        {St[2 * s + 1][0], St[2 * s + 1][1], St[2 * s + 1][2], St[2 * s + 1][3]}};
-                uint2 h0, l0, h1, l1;
-                split4(sv[0], h0, l0);
-                split4(sv[1], h1, l1);
-                const b8v s_hi = __builtin_bit_cast(b8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
-                const b8v s_lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
-                const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
-                const b8v zh = ld_b8_2x4(p0 + A_ZRH * ARR, p0 + A_ZRH * ARR + 32);
-                const b8v zl = ld_b8_2x4(p0 + A_ZRL * ARR, p0 + A_ZRL * ARR + 32);
-                yt = mfma32(s_hi, zh, yt);
-                yt = mfma32(s_hi, zl, yt);
-                yt = mfma32(s_lo, zh, yt);
-            }
-            {   // store: lane holds y[token x][j = 16wv + 4g + q]
-                const int p = grp * GRP + blk * BLK + x;
+            for (int tt = 0; tt < 4; ++tt) {
+                const int p = grp * GRP + wv * BLK + 4 * tq + tt;
+                pr[tt] = pk[tt] = pv[tt] = pw[tt] = make_uint2(0u, 0u);
+                pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p < ntok) {
                     const int t = a.reverse ? ntok - 1 - p : p;
-                    const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
-                    float o[4] = {yt[0], yt[1], yt[2], yt[3]};
-                    if (a.accumulate) {
-                        float old[4];
-                        if (a.y_f32) io4<float>::load(a.y_f32 + idx, old);
-                        else io4<bf16_t>::load(gy_ + idx, old);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] += old[q];
-                    }
-                    if (a.y_f32 && !a.accumulate) io4<float>::store(a.y_f32 + idx, o);
-                    else io4<bf16_t>::store(gy_ + idx, o);
+                    const long idx = base + (long)t * a.C + 4 * c4;
+                    if constexpr (!STATE_ONLY) pr[tt] = *reinterpret_cast<const uint2*>(gr_ + idx);
+                    pk[tt] = *reinterpret_cast<const uint2*>(gk_ + idx);
+                    pv[tt] = *reinterpret_cast<const uint2*>(gv_ + idx);
+                    if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + idx);
+                    else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + idx);
                 }
             }
-            }   // !STATE_ONLY
-            // (4) S[it] <- e^{c16} (.) S[it] + Kz^T V
+        };
+        auto prep_group = [&](int grp, int buf) {
+            char* const bb = smem + buf * GRP_BYTES + wv * BLK_BYTES;
+            float r[4][4], k[4][4], cs[4][4];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const float4 d = *reinterpret_cast<const float4*>(bb + OFF_D + (16 * it + 4 * g) * 4);
-                f4v acc = {St[it][0] * d.x, St[it][1] * d.y, St[it][2] * d.z, St[it][3] * d.w};
-                const s4v zkh = tr_read(bb + A_ZKH * ARR + troff + 32 * it);
-                const s4v zkl = tr_read(bb + A_ZKL * ARR + troff + 32 * it);
-                acc = mfma16(zkh, vf, acc);
-                acc = mfma16(zkl, vf, acc);
-                St[it] = acc;
+            for (int tt = 0; tt < 4; ++tt) {
+                const bool valid = grp * GRP + wv * BLK + 4 * tq + tt < ntok;
+                r[tt][0] = bf_lo(pr[tt].x); r[tt][1] = bf_hi(pr[tt].x); r[tt][2] = bf_lo(pr[tt].y); r[tt][3] = bf_hi(pr[tt].y);
+                k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
+                float lw[4];
+                if constexpr (W_RAW) {
+                    lw[0] = -__expf(bf_lo(pw[tt].x)); lw[1] = -__expf(bf_hi(pw[tt].x));
+                    lw[2] = -__expf(bf_lo(pw[tt].y)); lw[3] = -__expf(bf_hi(pw[tt].y));
+                } else {
+                    lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float l = valid ? fmaxf(lw[c], LW_MIN) : 0.f;
+                    cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + l;          // inclusive, within this lane's 4 tokens
+                }
+                if constexpr (!STATE_ONLY) {
+                    // bonus coefficient of the diagonal: sum over the 64 channels = 4 in-lane x 16 lanes of the row
+                    float part = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) part = fmaf(r[tt][c] * uu[c], k[tt][c], part);
+                    part = row_sum16(part);
+                    if (c4 == 0) *reinterpret_cast<float*>(bb + OFF_COEF + (4 * tq + tt) * 4) = part;
+                }
+                *reinterpret_cast<uint2*>(bb + A_V * ARR + (4 * tq + tt) * RSB + 8 * c4) = pv[tt];
             }
+            float pre[4], c8[4], c16[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float inc = cs[3][c];
+                float t = __shfl_up(inc, 16);
+                if (tq >= 1) inc += t;
+                t = __shfl_up(inc, 32);
+                if (tq >= 2) inc += t;
+                pre[c] = inc - cs[3][c];                                 // decay accumulated before this lane's tokens
+                c8[c] = __shfl(pre[c], 32 + c4);                         // ... before token 8
+                c16[c] = __shfl(inc, 48 + c4);                           // whole block
+            }
+            if (tq == 0) {
+                *reinterpret_cast<float4*>(bb + OFF_E8 + 16 * c4) =
+                    make_float4(__expf(c8[0]), __expf(c8[1]), __expf(c8[2]), __expf(c8[3]));
+                *reinterpret_cast<float4*>(bb + OFF_E16 + 16 * c4) =
+                    make_float4(__expf(c16[0]), __expf(c16[1]), __expf(c16[2]), __expf(c16[3]));
+                *reinterpret_cast<float4*>(bb + OFF_E16M8 + 16 * c4) =
+                    make_float4(__expf(c16[0] - c8[0]), __expf(c16[1] - c8[1]), __expf(c16[2] - c8[2]), __expf(c16[3] - c8[3]));
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                float rh[4], kh[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float cex = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
+                    const float cin = pre[c] + cs[tt][c];
+                    rh[c] = r[tt][c] * __expf(cex - c8[c]);
+                    kh[c] = k[tt][c] * __expf(c8[c] - cin);
+                }
+                char* const row = bb + (4 * tq + tt) * RSB + 8 * c4;
+                uint2 hi, lo;
+                if constexpr (!STATE_ONLY) {
+                    split4(rh, hi, lo);
+                    *reinterpret_cast<uint2*>(row + A_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_RL * ARR) = lo;
+                }
+                split4(kh, hi, lo);
+                *reinterpret_cast<uint2*>(row + A_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_KL * ARR) = lo;
+            }
+        };
+
+        if (ngrp > 0) {
+            load_group(0);
+            prep_group(0, 0);
+            if (ngrp > 1) load_group(1);
         }
         __syncthreads();
-    }
-
-    if (a.s_out) {
-        bf16_t* const so = reinterpret_cast<bf16_t*>(a.s_out) + ((long)b * a.H + h) * HEAD * HEAD;
+        for (int grp = 0; grp < ngrp; ++grp) {
+            if (grp + 1 < ngrp) {
+                prep_group(grp + 1, (grp + 1) & 1);
+                if (grp + 2 < ngrp) load_group(grp + 2);
+            }
+            __syncthreads();
+        }
+    } else {
+        // ============================== consumer: value columns [16wv, 16wv+16) =========================
+        // lane (x = lane&15, g = lane>>4) holds S[i = 16it + 4g + q][j = 16wv + x] in St[it][q]
+        const int x = lane & 15, g = lane >> 4;
+        f4v St[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const float t4[4] = {St[it][0], St[it][1], St[it][2], St[it][3]};
-            io4<bf16_t>::store(so + (long)(16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
+            float t4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.s0)
+                io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.s0) + (long)b * a.s0_bstride +
+                                  ((long)h * HEAD + 16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
+            St[it] = f4v{t4[0], t4[1], t4[2], t4[3]};
+        }
+        const int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
+        __syncthreads();
+        for (int grp = 0; grp < ngrp; ++grp) {
+            if (a.ckpt) {
+                float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + GRP - 1) / GRP) + grp) * (HEAD * HEAD);
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    *reinterpret_cast<float4*>(ck + ((wv * 4 + it) * 64 + lane) * 4) =
+                        make_float4(St[it][0], St[it][1], St[it][2], St[it][3]);
+            }
+            const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
+            for (int blk = 0; blk < nb; ++blk) {
+                const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
+                // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
+                const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);
+                if constexpr (!STATE_ONLY) {
+                    // (1) transposed scores sc[b][a] = sum_i Khat[b][i] Rhat[a][i]; lane: column a = x, rows b = 4g+q
+                    f4v sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int off = x * RSB + (32 * s + 8 * g) * 2;
+                        const b8v kh = ld_b8(bb + A_KH * ARR + off), kl = ld_b8(bb + A_KL * ARR + off);
+                        const b8v rh = ld_b8(bb + A_RH * ARR + off), rl = ld_b8(bb + A_RL * ARR + off);
+                        sc = mfma32(kh, rh, sc);
+                        sc = mfma32(kh, rl, sc);
+                        sc = mfma32(kl, rh, sc);
+                    }
+                    const float cf = *reinterpret_cast<const float*>(bb + OFF_COEF + x * 4);
+                    float scm[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int bt = 4 * g + q;                        // key token; query token = x
+                        scm[q] = bt < x ? sc[q] : (bt == x ? cf : 0.f);
+                    }
+                    uint2 sh, sl;
+                    split4(scm, sh, sl);
+                    const s4v sc_hi = __builtin_bit_cast(s4v, sh), sc_lo = __builtin_bit_cast(s4v, sl);
+                    // (2) y^T[j][a] = sum_b V[b][j] sc[b][a]
+                    f4v yt = {0.f, 0.f, 0.f, 0.f};
+                    yt = mfma16(vf, sc_hi, yt);
+                    yt = mfma16(vf, sc_lo, yt);
+                    // (3) y^T[j][a] += sum_i (E8 S)[i][j] Rhat[a][i]; k-slot (s,g,e) <-> channel 32s + 16(e>>2) + 4g + (e&3)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float4 m0 = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 4 * g) * 4);
+                        const float4 m1 = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 16 + 4 * g) * 4);
+                        const float t0[4] = {St[2 * s][0] * m0.x, St[2 * s][1] * m0.y, St[2 * s][2] * m0.z, St[2 * s][3] * m0.w};
+                        const float t1[4] = {St[2 * s + 1][0] * m1.x, St[2 * s + 1][1] * m1.y,
+                                             St[2 * s + 1][2] * m1.z, St[2 * s + 1][3] * m1.w};
+                        uint2 h0, l0, h1, l1;
+                        split4(t0, h0, l0);
+                        split4(t1, h1, l1);
+                        const b8v s_hi = __builtin_bit_cast(b8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                        const b8v s_lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                        const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
+                        const b8v zh = ld_b8_2x4(p0 + A_RH * ARR, p0 + A_RH * ARR + 32);
+                        const b8v zl = ld_b8_2x4(p0 + A_RL * ARR, p0 + A_RL * ARR + 32);
+                        yt = mfma32(s_hi, zh, yt);
+                        yt = mfma32(s_hi, zl, yt);
+                        yt = mfma32(s_lo, zh, yt);
+                    }
+                    {   // store: lane holds y[token x][j = 16wv + 4g + q]
+                        const int p = grp * GRP + blk * BLK + x;
+                        if (p < ntok) {
+                            const int t = a.reverse ? ntok - 1 - p : p;
+                            const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
+                            float o[4] = {yt[0], yt[1], yt[2], yt[3]};
+                            if (a.accumulate) {
+                                float old[4];
+                                if (a.y_f32) io4<float>::load(a.y_f32 + idx, old);
+                                else io4<bf16_t>::load(gy_ + idx, old);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) o[q] += old[q];
+                            }
+                            if (a.y_f32 && !a.accumulate) io4<float>::store(a.y_f32 + idx, o);
+                            else io4<bf16_t>::store(gy_ + idx, o);
+                        }
+                    }
+                }
+                // (4) S[it] <- E16 (.) S[it] + E16m8 (.) (Khat^T V)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const s4v kh = tr_read(bb + A_KH * ARR + troff + 32 * it);
+                    const s4v kl = tr_read(bb + A_KL * ARR + troff + 32 * it);
+                    f4v o = {0.f, 0.f, 0.f, 0.f};
+                    o = mfma16(kh, vf, o);
+                    o = mfma16(kl, vf, o);
+                    const float4 d16 = *reinterpret_cast<const float4*>(bb + OFF_E16 + (16 * it + 4 * g) * 4);
+                    const float4 dm = *reinterpret_cast<const float4*>(bb + OFF_E16M8 + (16 * it + 4 * g) * 4);
+                    St[it][0] = fmaf(d16.x, St[it][0], dm.x * o[0]);
+                    St[it][1] = fmaf(d16.y, St[it][1], dm.y * o[1]);
+                    St[it][2] = fmaf(d16.z, St[it][2], dm.z * o[2]);
+                    St[it][3] = fmaf(d16.w, St[it][3], dm.w * o[3]);
+                }
+            }
+            __syncthreads();
+        }
+        if (a.s_out) {
+            bf16_t* const so = reinterpret_cast<bf16_t*>(a.s_out) + ((long)b * a.H + h) * HEAD * HEAD;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float t4[4] = {St[it][0], St[it][1], St[it][2], St[it][3]};
+                io4<bf16_t>::store(so + (long)(16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
+            }
         }
     }
-    if (a.zero_tail && !a.accumulate) {
+    if (!STATE_ONLY && a.zero_tail && !a.accumulate) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = ntok + (tid >> 4); t < a.T; t += 16) io4<bf16_t>::store(gy_ + base + (long)t * a.C + 4 * c4, z);
+        for (int t = ntok + (tid >> 4); t < a.T; t += 32)
+            io4<bf16_t>::store(gy_ + base + (long)t * a.C + 4 * (tid & 15), z);
     }
 }
 
 template <bool W_RAW, bool STATE_ONLY> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)NBLK * BLK_BYTES;
+    constexpr size_t lds = 2 * (size_t)GRP_BYTES;
     static bool configured = false;            // per instantiation; the attribute is per function, set once
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY>),
@@ -283,7 +305,7 @@ template <bool W_RAW, bool STATE_ONLY> hipError_t launch_fwd_variant(const ScanA
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY>), dim3(a.B * a.H), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY>), dim3(a.B * a.H), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -294,7 +316,7 @@ hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st)
     return a.wkind ? launch_fwd_variant<true, false>(a, st) : launch_fwd_variant<false, false>(a, st);
 }
 
-// state recurrence only, dumping the group-entry states into a.ckpt (first half of the chunked backward)
+// state recurrence only, dumping the group-entry states into a.ckpt (first half of the self-contained backward)
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st)
 {
     return a.wkind ? launch_fwd_variant<true, true>(a, st) : launch_fwd_variant<false, true>(a, st);

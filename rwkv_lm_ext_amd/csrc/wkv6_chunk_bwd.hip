@@ -476,7 +476,8 @@ hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
 {
     ScanArgs sp = a;                       // state pass: same inputs, no outputs, dump group-entry states
     sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
-    if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
+    if (!a.ckpt_valid)
+        if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
     return a.wkind ? launch_bwd_variant<true>(a, st) : launch_bwd_variant<false>(a, st);
 }
 

@@ -38,6 +38,7 @@ struct ScanArgs {
     void* gs;                         // [B,H,N,N] per-batch dL/dS0, I/O type (null: skip)
     float* aux;                       // [B,T,C] fp32 scratch carrying a_t from sweep S to sweep G
     float* ckpt;                      // chunked path: [B*H][ceil(T/64)][4096] fp32 group-entry states (state pass -> backward)
+    int ckpt_valid;                   // backward: ckpt was filled by the forward, skip the state pass
     const int* lens;                  // per-batch number of tokens to scan (null: T)
     int reverse;                      // 1: scan tokens lens-1 .. 0
     int use_u;                        // 0: bonus u treated as 0 (reverse half of wkv6_bi)

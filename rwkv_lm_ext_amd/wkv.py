@@ -45,7 +45,10 @@ class WKV_6(torch.autograd.Function):
             _assert_inputs(C, H, r, k, v, w, u)
             ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
             ctx.save_for_backward(r, k, v, w, u)
-            return wkv6_op.forward_ex(r, k, v, w, u, H)
+            # when a backward will follow, let the forward store its per-64-token state checkpoints (fp32, 4 B per
+            # token-channel) so the backward does not have to recompute them with a state pass
+            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
+            return wkv6_op.forward_ex(r, k, v, w, u, H, ckpt=ctx.ckpt)
 
     @staticmethod
     def backward(ctx, gy):
@@ -53,7 +56,8 @@ class WKV_6(torch.autograd.Function):
             assert gy.dtype == torch.bfloat16
             gy = gy.contiguous()
             r, k, v, w, u = ctx.saved_tensors
-            gr, gk, gv, gw, gu, _ = wkv6_op.backward_ex(r, k, v, w, u, gy, ctx.H)
+            gr, gk, gv, gw, gu, _ = wkv6_op.backward_ex(r, k, v, w, u, gy, ctx.H, ckpt=ctx.ckpt)
+            ctx.ckpt = None
             gu = _sum_bf16(gu, (ctx.H, ctx.C // ctx.H))
             return (None, None, None, None, gr, gk, gv, gw, gu)
 

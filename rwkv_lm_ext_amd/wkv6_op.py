@@ -160,7 +160,13 @@ wkv6infctx_cuda = _Wkv6Infctx
 
 
 # ---- generic entry used by the autograd layer (raw bf16 decay, optional fp32 I/O, explicit state) ----
-def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None, algo=None):
+def new_checkpoint(B, T, C, H, device):
+    """Buffer for the forward-state checkpoints that `forward_ex(..., ckpt=)` fills and `backward_ex(..., ckpt=)`
+    consumes (also usable as the backward workspace)."""
+    return torch.empty(_lib.load().wkv6_backward_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=device)
+
+
+def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None, algo=None, ckpt=None):
     """y = WKV6(r,k,v,w,u[,s0]) with the I/O type of `r` (bf16, or fp32 for numerics tests).
     algo: None (library default: chunked MFMA kernel for bf16 I/O) or "scan" (exact token-serial kernels)."""
     B, T, C = r.shape
@@ -183,13 +189,17 @@ def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None, alg
     named["y"] = (y, btc, io)
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     with torch.cuda.device(dev):
-        rc = _lib.load().wkv6_forward_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(s0),
-                                         _ptr(s_out), _ptr(y), flags, _stream_ptr())
+        if ckpt is not None:       # training forward: also store the per-group state checkpoints for the backward
+            rc = _lib.load().wkv6_forward_ckpt_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(s0),
+                                                  _ptr(s_out), _ptr(y), _ptr(ckpt), ckpt.numel(), flags, _stream_ptr())
+        else:
+            rc = _lib.load().wkv6_forward_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(s0),
+                                             _ptr(s_out), _ptr(y), flags, _stream_ptr())
     _lib.check(rc, "wkv6 forward_ex")
     return y
 
 
-def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False, algo=None):
+def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False, algo=None, ckpt=None):
     """Returns (gr, gk, gv, gw, gu[B,C], gs[B,H,N,N] or None) in the I/O type of `r`."""
     B, T, C = r.shape
     io = r.dtype
@@ -207,7 +217,11 @@ def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False, alg
     gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
     gu = torch.empty((B, C), device=dev, dtype=io)
     gs = torch.empty((B, H, HEAD_SIZE, HEAD_SIZE), device=dev, dtype=io) if want_gs else None
-    ws = torch.empty(_lib.load().wkv6_backward_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+    if ckpt is not None:           # checkpoints written by forward_ex(..., ckpt=ckpt) on the same inputs
+        ws = ckpt
+        flags |= _lib.CKPT_VALID
+    else:
+        ws = torch.empty(_lib.load().wkv6_backward_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.load().wkv6_backward_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(s0),
                                           _ptr(gy), _ptr(gr), _ptr(gk), _ptr(gv), _ptr(gw), _ptr(gu), _ptr(gs),

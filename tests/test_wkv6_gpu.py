@@ -376,3 +376,21 @@ def test_chunk_backward_agrees_with_scan(ops):
         same = float(np.mean(c[big] == s_[big]))
         rel = float((np.abs(c - s_)[big] / np.abs(s_[big])).max())
         assert same >= 0.97 and rel <= 2.0 ** -7 * (2.02 if n == "gw" else 1.01), (n, same, rel)
+
+
+def test_forward_checkpoints_feed_backward(ops, oracle):
+    """Training path: forward_ex(ckpt=) stores the per-group states, backward_ex(ckpt=) consumes them; results
+    must be identical (bitwise) to the self-contained backward that recomputes them with its own state pass."""
+    B, T, H = 2, 333, 2
+    r, k, v, w, u, gy = rand_inputs(91, B, T, H, "stress")
+    bf = torch.bfloat16
+    d = [dev(t, bf) for t in (r, k, v, w, u, gy)]
+    ck = ops.new_checkpoint(B, T, H * 64, H, "cuda")
+    y1 = ops.forward_ex(*d[:5], H, ckpt=ck)
+    y0 = ops.forward_ex(*d[:5], H)
+    assert torch.equal(y0, y1)
+    g1 = ops.backward_ex(*d, H, ckpt=ck)
+    g0 = ops.backward_ex(*d, H)
+    for a_, b_ in zip(g0[:5], g1[:5]):
+        assert torch.equal(a_, b_)
+    check(g1[3], oracle.backward(r, k, v, w, u, gy)["gw"], bf, "ckpt path gw")
