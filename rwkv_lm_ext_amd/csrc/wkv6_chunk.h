@@ -12,7 +12,8 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int BLK = 16;                       // tokens per block
 constexpr int NBLK = 4;                       // blocks per group (= waves)
 constexpr int GRP = BLK * NBLK;               // 64 tokens per group
-constexpr int RSB = 144;                      // bytes per staged token row (64 bf16 + 8 pad): conflict-free b128 reads
+constexpr int RSB = 160;                      // bytes per staged token row (64 bf16 + 16 pad): ds_read_b128 row reads and
+                                              // ds_read_b64_tr_b16 are both conflict-free at this stride (144 B is 2-way on both)
 constexpr int ARR = BLK * RSB;                // one operand array
 enum { A_RH = 0, A_RL, A_KH, A_KL, A_V, N_ARR };       // forward operand arrays, bf16 [16][72] each
 constexpr int OFF_E8 = N_ARR * ARR;                    // float[64]  e^{c_8}

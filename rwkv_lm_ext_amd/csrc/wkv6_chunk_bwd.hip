@@ -13,14 +13,18 @@
 //   gu       += vg_a r_a (.) k_a
 // i.e. the adjoint of cuda/wkv6_cuda.cu:44-57 (reference backward: cuda/wkv6_cuda.cu:63-227), re-associated.
 //
-// The forward states are needed in reverse order: a state-only pass of the forward kernel
-// (launch_chunk_state_pass) dumps the state at the entry of every 64-token group (fp32) into the workspace; this
-// kernel walks the groups backwards, rebuilds the three intermediate block states of a group in registers and
-// then processes its four blocks in reverse.
+// The forward states are needed in reverse order: the forward kernel (or, for a self-contained backward, its
+// state-only variant, launch_chunk_state_pass) dumps the state at the entry of every 64-token group (fp32) into
+// the workspace; this kernel walks the groups backwards, rebuilds the three intermediate block states of a group
+// in registers and then processes its four blocks in reverse.
 //
-// One 256-thread workgroup per (batch, head).  Wave w owns key rows [16w,16w+16) for gr/gk/gw (state tiles held
-// transposed: lane = key row) and value columns [16w,16w+16) for gv; G is kept in both orientations because gk
-// contracts it over j and gv over i.
+// One 512-thread workgroup (8 wave64) per (batch, head), one barrier pair per group:
+//   phase P (all 8 waves): waves w and w+4 turn the two channel halves of block w into operands in LDS
+//            (lane = 4 channels x 2 tokens);
+//   phase C: "row" waves 0..3 own key rows [16w,16w+16): forward states and G with lane = key row; they produce
+//            gr, gk, gw, gu.  "column" waves 4..7 own value columns [16w,16w+16): G with lane = value column;
+//            they produce the scores, gv and gs.  G is kept in both orientations because gk contracts it over j
+//            and gv over i.  A row wave and a column wave share each SIMD, so their VALU/MFMA streams interleave.
 #include "wkv6_chunk.h"
 
 namespace wkv6 {
@@ -30,16 +34,16 @@ namespace {
 
 using namespace chunk;
 
-enum { B_RH = 0, B_RL, B_KH, B_KL, B_V, B_GY, B_R, B_K, NB_ARR };      // bf16 [16][72] each
-constexpr int FRS = 68 * 4;                                            // bytes per fp32 token row (64 + 4 pad)
-constexpr int BOFF_CEX = NB_ARR * ARR;                                 // float [16][68]  c_a (exclusive)
-constexpr int BOFF_LW = BOFF_CEX + BLK * FRS;                          // float [16][68]  lw_a (unclamped)
-constexpr int BOFF_C8 = BOFF_LW + BLK * FRS;                           // float [64]
-constexpr int BOFF_E8 = BOFF_C8 + 256;
+enum { B_RH = 0, B_RL, B_KH, B_KL, B_V, B_GY, B_R, B_K, NB_ARR };      // bf16 [16][RSB/2] each
+constexpr int FRS = 72 * 4;                                            // bytes per fp32 token row (conflict-free float4 row reads)
+constexpr int BOFF_FR = NB_ARR * ARR;                                  // float [16][72]  fR_a = e^{c_a - c_8}
+constexpr int BOFF_FK = BOFF_FR + BLK * FRS;                           // float [16][72]  fK_a = e^{c_8 - c_{a+1}}
+constexpr int BOFF_LW = BOFF_FK + BLK * FRS;                           // float [16][72]  lw_a e^{lw_a - max(lw_a, LW_MIN)}
+constexpr int BOFF_E8 = BOFF_LW + BLK * FRS;                           // float [64]
 constexpr int BOFF_E16 = BOFF_E8 + 256;
 constexpr int BOFF_E16M8 = BOFF_E16 + 256;
-constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float [16]  sum_i r u k
-constexpr int BBLK_BYTES = BOFF_COEF + 64;                             // 28224
+constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float [2][16]  per-half sum_i r u k
+constexpr int BBLK_BYTES = BOFF_COEF + 128;
 
 constexpr int DPP_SHL1 = 0x101, DPP_SHL2 = 0x102, DPP_SHL4 = 0x104, DPP_SHL8 = 0x108;   // row_shl:n, zero fill
 
@@ -62,10 +66,14 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 }
 
 template <bool W_RAW>
-__global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
+__global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [NBLK][BBLK_BYTES]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool rowrole = wid < 4;
+    const int wv = wid & 3;                                              // tile owned in phase C, block prepared in phase P
+    const int half = wid >> 2;                                           // channel half prepared in phase P
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r);
     const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k);
@@ -80,33 +88,23 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
     const long base = (long)b * a.T * a.C + (long)h * HEAD;
     const int ngmax = (a.T + GRP - 1) / GRP;
 
-    const int c4 = lane & 15, tq = lane >> 4;            // phase-P role
-    const int x = lane & 15, g = lane >> 4;              // phase-C role
-    float uu[4] = {0.f, 0.f, 0.f, 0.f}, ue[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.use_u) {
-        io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 4 * c4, uu);
-        io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
-    }
+    // ---- phase-P role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block wv
+    const int c8i = lane & 7, tq = lane >> 3;
+    const int ch0 = 32 * half + 4 * c8i;
+    float uu[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + ch0, uu);
 
-    // ST[blk][jt][q] = S_entry(blk)[i = 16wv + x][j = 16jt + 4g + q]      (transposed tiles: lane = key row)
-    // GI[jt][q]      = G[i = 16wv + x][j = 16jt + 4g + q]
-    // GJ[it][q]      = G[i = 16it + 4g + q][j = 16wv + x]
-    f4v ST[4][4], GI[4], GJ[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { GI[t] = f4v{0.f, 0.f, 0.f, 0.f}; GJ[t] = f4v{0.f, 0.f, 0.f, 0.f}; }
-    float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
-
-    uint2 pr[4], pk[4], pv[4], pg[4], pw[4];
-    float4 pe[4];
+    uint2 pr[2], pk[2], pv[2], pg[2], pw[2];
+    float4 pe[2];
     auto load_group = [&](int grp) {
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int p = grp * GRP + wv * BLK + 4 * tq + tt;
+        for (int tt = 0; tt < 2; ++tt) {
+            const int p = grp * GRP + wv * BLK + 2 * tq + tt;
             pr[tt] = pk[tt] = pv[tt] = pg[tt] = pw[tt] = make_uint2(0u, 0u);
             pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < ntok) {
                 const int t = a.reverse ? ntok - 1 - p : p;
-                const long idx = base + (long)t * a.C + 4 * c4;
+                const long idx = base + (long)t * a.C + ch0;
                 pr[tt] = *reinterpret_cast<const uint2*>(gr_ + idx);
                 pk[tt] = *reinterpret_cast<const uint2*>(gk_ + idx);
                 pv[tt] = *reinterpret_cast<const uint2*>(gv_ + idx);
@@ -119,10 +117,10 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
 
     auto prep_group = [&](int grp) {
         char* const bb = smem + wv * BBLK_BYTES;
-        float r[4][4], k[4][4], cs[4][4], lws[4][4];
+        float r[2][4], k[2][4], cs[2][4], lws[2][4];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const bool valid = grp * GRP + wv * BLK + 4 * tq + tt < ntok;
+        for (int tt = 0; tt < 2; ++tt) {
+            const bool valid = grp * GRP + wv * BLK + 2 * tq + tt < ntok;
             r[tt][0] = bf_lo(pr[tt].x); r[tt][1] = bf_hi(pr[tt].x); r[tt][2] = bf_lo(pr[tt].y); r[tt][3] = bf_hi(pr[tt].y);
             k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
             float lw[4];
@@ -132,186 +130,318 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
             } else {
                 lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
             }
+            float lwe[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                lws[tt][c] = valid ? lw[c] : 0.f;                         // true log decay (for gw)
-                cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + fmaxf(lws[tt][c], LW_MIN);
+                lws[tt][c] = valid ? fmaxf(lw[c], LW_MIN) : 0.f;          // the decay the block algebra uses
+                cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + lws[tt][c];
+                // gw multiplier: the true lw, times d_true / d_clamped where the clamp is active (the algebra yields the
+                // exact gradient of the clamped model, d_clamped * X; the true one is d_true * X)
+                lwe[c] = valid ? lw[c] * __expf(fminf(lw[c] - LW_MIN, 0.f)) : 0.f;
             }
             float part = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) part = fmaf(r[tt][c] * uu[c], k[tt][c], part);
-            part = row_sum16(part);
-            char* const row = bb + (4 * tq + tt) * RSB + 8 * c4;
-            if (c4 == 0) *reinterpret_cast<float*>(bb + BOFF_COEF + (4 * tq + tt) * 4) = part;
+            part += dpp_mov<DPP_XOR1>(part);
+            part += dpp_mov<DPP_XOR2>(part);
+            part += __shfl_xor(part, 4);                                  // the 8 lanes that share this token
+            const int tok = 2 * tq + tt;
+            char* const row = bb + tok * RSB + ch0 * 2;
+            if (c8i == 0) *reinterpret_cast<float*>(bb + BOFF_COEF + (half * 16 + tok) * 4) = part;
             *reinterpret_cast<uint2*>(row + B_V * ARR) = pv[tt];
             *reinterpret_cast<uint2*>(row + B_GY * ARR) = pg[tt];
             *reinterpret_cast<uint2*>(row + B_R * ARR) = pr[tt];
             *reinterpret_cast<uint2*>(row + B_K * ARR) = pk[tt];
-            *reinterpret_cast<float4*>(bb + BOFF_LW + (4 * tq + tt) * FRS + 16 * c4) =
-                make_float4(lws[tt][0], lws[tt][1], lws[tt][2], lws[tt][3]);
+            *reinterpret_cast<float4*>(bb + BOFF_LW + tok * FRS + ch0 * 4) = make_float4(lwe[0], lwe[1], lwe[2], lwe[3]);
         }
         float pre[4], c8[4], c16[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float inc = cs[3][c];
-            float t = __shfl_up(inc, 16);
+            float inc = cs[1][c];                                        // inclusive prefix over the 8 token-pair lanes
+            float t = __shfl_up(inc, 8);
             if (tq >= 1) inc += t;
-            t = __shfl_up(inc, 32);
+            t = __shfl_up(inc, 16);
             if (tq >= 2) inc += t;
-            pre[c] = inc - cs[3][c];
-            c8[c] = __shfl(pre[c], 32 + c4);
-            c16[c] = __shfl(inc, 48 + c4);
+            t = __shfl_up(inc, 32);
+            if (tq >= 4) inc += t;
+            pre[c] = inc - cs[1][c];
+            c8[c] = __shfl(pre[c], 32 + c8i);                            // before token 8  (lane tq = 4)
+            c16[c] = __shfl(inc, 56 + c8i);                              // whole block     (lane tq = 7)
         }
         if (tq == 0) {
-            *reinterpret_cast<float4*>(bb + BOFF_C8 + 16 * c4) = make_float4(c8[0], c8[1], c8[2], c8[3]);
-            *reinterpret_cast<float4*>(bb + BOFF_E8 + 16 * c4) =
+            *reinterpret_cast<float4*>(bb + BOFF_E8 + ch0 * 4) =
                 make_float4(__expf(c8[0]), __expf(c8[1]), __expf(c8[2]), __expf(c8[3]));
-            *reinterpret_cast<float4*>(bb + BOFF_E16 + 16 * c4) =
+            *reinterpret_cast<float4*>(bb + BOFF_E16 + ch0 * 4) =
                 make_float4(__expf(c16[0]), __expf(c16[1]), __expf(c16[2]), __expf(c16[3]));
-            *reinterpret_cast<float4*>(bb + BOFF_E16M8 + 16 * c4) =
+            *reinterpret_cast<float4*>(bb + BOFF_E16M8 + ch0 * 4) =
                 make_float4(__expf(c16[0] - c8[0]), __expf(c16[1] - c8[1]), __expf(c16[2] - c8[2]), __expf(c16[3] - c8[3]));
         }
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            float rh[4], kh[4], cex[4];
+        for (int tt = 0; tt < 2; ++tt) {
+            float rh[4], kh[4], fr[4], fk[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                cex[c] = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
+                const float cex = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
                 const float cin = pre[c] + cs[tt][c];
-                rh[c] = r[tt][c] * __expf(cex[c] - c8[c]);
-                kh[c] = k[tt][c] * __expf(c8[c] - cin);
+                fr[c] = __expf(cex - c8[c]);
+                fk[c] = __expf(c8[c] - cin);
+                rh[c] = r[tt][c] * fr[c];
+                kh[c] = k[tt][c] * fk[c];
             }
-            char* const row = bb + (4 * tq + tt) * RSB + 8 * c4;
+            const int tok = 2 * tq + tt;
+            char* const row = bb + tok * RSB + ch0 * 2;
             uint2 hi, lo;
             split4(rh, hi, lo);
             *reinterpret_cast<uint2*>(row + B_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + B_RL * ARR) = lo;
             split4(kh, hi, lo);
             *reinterpret_cast<uint2*>(row + B_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + B_KL * ARR) = lo;
-            *reinterpret_cast<float4*>(bb + BOFF_CEX + (4 * tq + tt) * FRS + 16 * c4) =
-                make_float4(cex[0], cex[1], cex[2], cex[3]);
+            *reinterpret_cast<float4*>(bb + BOFF_FR + tok * FRS + ch0 * 4) = make_float4(fr[0], fr[1], fr[2], fr[3]);
+            *reinterpret_cast<float4*>(bb + BOFF_FK + tok * FRS + ch0 * 4) = make_float4(fk[0], fk[1], fk[2], fk[3]);
         }
     };
 
+    // ---- phase-C role
+    const int x = lane & 15, g = lane >> 4;
+    const int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
     const int ngrp = (ntok + GRP - 1) / GRP;
     if (ngrp > 0) load_group(ngrp - 1);
-    for (int grp = ngrp - 1; grp >= 0; --grp) {
-        {   // group-entry forward state from the state pass (dumped in the forward kernel's register order)
-            const float* const ck = a.ckpt + ((long)blockIdx.x * ngmax + grp) * (HEAD * HEAD);
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                float t4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    t4[q] = ck[((jt * 4 + wv) * 64 + 16 * (x >> 2) + 4 * g + q) * 4 + (x & 3)];
-                ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
-            }
-        }
-        prep_group(grp);
-        __syncthreads();
-        if (grp > 0) load_group(grp - 1);
-        const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
-        const int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
 
-        // ---- rebuild the entry states of blocks 1..3:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
+    if (rowrole) {
+        // =============== key rows [16wv, 16wv+16): gr, gk, gw, gu ==========================================
+        // ST[blk][jt][q] = S_entry(blk)[i = 16wv + x][j = 16jt + 4g + q]   (transposed tiles: lane = key row)
+        // GI[jt][q]      = G[i = 16wv + x][j = 16jt + 4g + q]
+        float ue[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
+        f4v ST[4][4], GI[4];
 #pragma unroll
-        for (int blk = 0; blk < NBLK - 1; ++blk) {
-            if (blk + 1 < nb) {
-                const char* const bb = smem + blk * BBLK_BYTES;
-                const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
-                const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
-                const float e16 = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
-                const float e16m8 = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
+        for (int t = 0; t < 4; ++t) GI[t] = f4v{0.f, 0.f, 0.f, 0.f};
+        float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
+
+        for (int grp = ngrp - 1; grp >= 0; --grp) {
+            {   // group-entry forward state (dumped in the forward kernel's register order)
+                const float* const ck = a.ckpt + ((long)blockIdx.x * ngmax + grp) * (HEAD * HEAD);
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
-                    const s4v vf = tr_read(bb + B_V * ARR + troff + 32 * jt);
-                    f4v o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma16(vf, khf, o);
-                    o = mfma16(vf, klf, o);
+                    float t4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) ST[blk + 1][jt][q] = fmaf(e16, ST[blk][jt][q], e16m8 * o[q]);
+                    for (int q = 0; q < 4; ++q)
+                        t4[q] = ck[((jt * 4 + wv) * 64 + 16 * (x >> 2) + 4 * g + q) * 4 + (x & 3)];
+                    ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
                 }
             }
-        }
+            prep_group(grp);
+            __syncthreads();
+            if (grp > 0) load_group(grp - 1);
+            const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
 
-        // ---- the four blocks in reverse
+            // ---- rebuild the entry states of blocks 1..3:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
 #pragma unroll
-        for (int blk = NBLK - 1; blk >= 0; --blk) {
-            if (blk < nb) {
+            for (int blk = 0; blk < NBLK - 1; ++blk) {
+                if (blk + 1 < nb) {
+                    const char* const bb = smem + blk * BBLK_BYTES;
+                    const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
+                    const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
+                    const float e16 = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
+                    const float e16m8 = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        const s4v vf = tr_read(bb + B_V * ARR + troff + 32 * jt);
+                        f4v o = {0.f, 0.f, 0.f, 0.f};
+                        o = mfma16(vf, khf, o);
+                        o = mfma16(vf, klf, o);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ST[blk + 1][jt][q] = fmaf(e16, ST[blk][jt][q], e16m8 * o[q]);
+                    }
+                }
+            }
+
+#pragma unroll
+            for (int blk = NBLK - 1; blk >= 0; --blk) {
+                if (blk < nb) {
+                    const char* const bb = smem + blk * BBLK_BYTES;
+                    // dA in both orientations (exact bf16 operands)
+                    f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int off = x * RSB + (32 * s + 8 * g) * 2;
+                        const b8v gyr = ld_b8(bb + B_GY * ARR + off), vr = ld_b8(bb + B_V * ARR + off);
+                        dA_ab = mfma32(gyr, vr, dA_ab);          // [row a][col b]: lane col b = x, rows a = 4g+q
+                        dA_ba = mfma32(vr, gyr, dA_ba);          // [row b][col a]: lane col a = x, rows b = 4g+q
+                    }
+                    // vg_x = dA[x][x]: held by lane (x, g = x>>2) in register x&3
+                    const float vg = __shfl(pick4(dA_ba, x & 3), 16 * (x >> 2) + x);
+                    float dab[4], dba[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int o = 4 * g + q;
+                        dab[q] = x < o ? dA_ab[q] : 0.f;          // dA[a = o][b = x], strictly lower
+                        dba[q] = o < x ? dA_ba[q] : 0.f;          // dA^T[b = o][a = x], strictly lower
+                    }
+                    uint2 th, tl;
+                    split4(dab, th, tl);
+                    const s4v dab_hi = __builtin_bit_cast(s4v, th), dab_lo = __builtin_bit_cast(s4v, tl);
+                    split4(dba, th, tl);
+                    const s4v dba_hi = __builtin_bit_cast(s4v, th), dba_lo = __builtin_bit_cast(s4v, tl);
+
+                    const s4v rhf_w = tr_read(bb + B_RH * ARR + troff + 32 * wv);      // Rhat[4g+e][16wv + x]
+                    const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
+                    const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
+                    const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
+                    const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
+                    const float e16x = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
+                    const float e16m8x = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
+
+                    // accumulators [i_local = 4g+q][token x]
+                    f4v accr = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float t0[4], t1[4];
+                        b8v hi, lo;
+                        const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q] * e8x; t1[q] = ST[blk][2 * s + 1][q] * e8x; }
+                        split8(t0, t1, hi, lo);
+                        const b8v gyp = ld_b8_2x4(p0 + B_GY * ARR, p0 + B_GY * ARR + 32);
+                        accr = mfma32(hi, gyp, accr);
+                        accr = mfma32(lo, gyp, accr);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
+                        split8(t0, t1, hi, lo);
+                        const b8v vp = ld_b8_2x4(p0 + B_V * ARR, p0 + B_V * ARR + 32);
+                        acck = mfma32(hi, vp, acck);
+                        acck = mfma32(lo, vp, acck);
+                    }
+                    accr = mfma16(khf, dba_hi, accr);                // sum_b Khat[b][i] dA[a][b]
+                    accr = mfma16(khf, dba_lo, accr);
+                    accr = mfma16(klf, dba_hi, accr);
+                    acck = mfma16(rhf_w, dab_hi, acck);              // sum_a Rhat[a][i] dA[a][b]
+                    acck = mfma16(rhf_w, dab_lo, acck);
+                    acck = mfma16(rlf_w, dab_hi, acck);
+                    {
+                        const int ch = 16 * wv + 4 * g;
+                        const float4 fr4 = *reinterpret_cast<const float4*>(bb + BOFF_FR + x * FRS + ch * 4);
+                        const float4 fk4 = *reinterpret_cast<const float4*>(bb + BOFF_FK + x * FRS + ch * 4);
+                        const float4 lw4 = *reinterpret_cast<const float4*>(bb + BOFF_LW + x * FRS + ch * 4);
+                        const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
+                        const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
+                        const float frv[4] = {fr4.x, fr4.y, fr4.z, fr4.w}, fkv[4] = {fk4.x, fk4.y, fk4.z, fk4.w};
+                        const float lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
+                        const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                        const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
+                        float o_gr[4], o_gk[4], o_gw[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float dq = frv[q] * accr[q];
+                            const float dk = fkv[q] * acck[q];
+                            o_gr[q] = fmaf(vg * ue[q], kv[q], dq);
+                            o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
+                            gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
+                            const float bt = kv[q] * dk;
+                            const float dl = rv[q] * dq - bt;
+                            float sfx = dl;                       // inclusive suffix sum over the later tokens of the row
+                            sfx += dpp_mov<DPP_SHL1>(sfx);
+                            sfx += dpp_mov<DPP_SHL2>(sfx);
+                            sfx += dpp_mov<DPP_SHL4>(sfx);
+                            sfx += dpp_mov<DPP_SHL8>(sfx);
+                            const float total = __shfl(sfx, lane & 48);
+                            o_gw[q] = (Rc[q] + (sfx - dl) - bt) * lwv[q];
+                            Rc[q] += total;
+                        }
+                        const int p = grp * GRP + blk * BLK + x;
+                        if (p < ntok) {
+                            const int t = a.reverse ? ntok - 1 - p : p;
+                            const long idx = base + (long)t * a.C + ch;
+                            if (a.accumulate) {
+                                float o1[4], o2[4], o3[4];
+                                io4<bf16_t>::load(ogr + idx, o1);
+                                io4<bf16_t>::load(ogk + idx, o2);
+                                io4<bf16_t>::load(ogw + idx, o3);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) { o_gr[q] += o1[q]; o_gk[q] += o2[q]; o_gw[q] += o3[q]; }
+                            }
+                            io4<bf16_t>::store(ogr + idx, o_gr);
+                            io4<bf16_t>::store(ogk + idx, o_gk);
+                            io4<bf16_t>::store(ogw + idx, o_gw);
+                        }
+                    }
+                    // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        const s4v gyf = tr_read(bb + B_GY * ARR + troff + 32 * jt);   // gy[4g+e][16jt + x]
+                        f4v o = {0.f, 0.f, 0.f, 0.f};
+                        o = mfma16(gyf, rhf_w, o);                   // [row j_local][col i_local = x]
+                        o = mfma16(gyf, rlf_w, o);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * o[q]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (a.gu) {
+            float s4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] = row_sum16(gu_acc[q]);
+            if (x == 0) io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.gu) + (long)b * a.C + h * HEAD + 16 * wv + 4 * g, s4);
+        }
+    } else {
+        // =============== value columns [16wv, 16wv+16): scores, gv, gs ======================================
+        // GJ[it][q] = G[i = 16it + 4g + q][j = 16wv + x]
+        f4v GJ[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) GJ[t] = f4v{0.f, 0.f, 0.f, 0.f};
+        for (int grp = ngrp - 1; grp >= 0; --grp) {
+            prep_group(grp);
+            __syncthreads();
+            if (grp > 0) load_group(grp - 1);
+            const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
+            for (int blk = nb - 1; blk >= 0; --blk) {
                 const char* const bb = smem + blk * BBLK_BYTES;
-                // dA in both orientations (exact bf16 operands) and the scores A[a][b]
-                f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
+                f4v sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int off = x * RSB + (32 * s + 8 * g) * 2;
-                    const b8v gyr = ld_b8(bb + B_GY * ARR + off), vr = ld_b8(bb + B_V * ARR + off);
-                    dA_ab = mfma32(gyr, vr, dA_ab);              // [row a][col b]: lane col b = x, rows a = 4g+q
-                    dA_ba = mfma32(vr, gyr, dA_ba);              // [row b][col a]: lane col a = x, rows b = 4g+q
                     const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
                     const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
-                    sc = mfma32(rh, kh, sc);                     // [row a][col b]
+                    sc = mfma32(rh, kh, sc);                     // A[row a][col b]: lane col b = x, rows a = 4g+q
                     sc = mfma32(rh, kl, sc);
                     sc = mfma32(rl, kh, sc);
                 }
-                // vg_x = dA[x][x]: held by lane (x, g = x>>2) in register x&3
-                const float vg = __shfl(pick4(dA_ba, x & 3), 16 * (x >> 2) + x);
-                const float4 cf4 = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 16 * g);
-                const float cfa[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
-                float scm[4], dab[4], dba[4];
+                const float4 cfa = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 16 * g);
+                const float4 cfb = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 64 + 16 * g);
+                const float cf[4] = {cfa.x + cfb.x, cfa.y + cfb.y, cfa.z + cfb.z, cfa.w + cfb.w};
+                float scm[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int o = 4 * g + q;                      // the "row" token of all three tiles
-                    scm[q] = x < o ? sc[q] : (x == o ? cfa[q] : 0.f);   // A[a = o][b = x], diagonal = bonus coefficient
-                    dab[q] = x < o ? dA_ab[q] : 0.f;              // dA[a = o][b = x], strictly lower
-                    dba[q] = o < x ? dA_ba[q] : 0.f;              // dA^T[b = o][a = x], strictly lower
+                    const int o = 4 * g + q;                      // query token a; key token b = x
+                    scm[q] = x < o ? sc[q] : (x == o ? cf[q] : 0.f);
                 }
                 uint2 th, tl;
                 split4(scm, th, tl);
                 const s4v sc_hi = __builtin_bit_cast(s4v, th), sc_lo = __builtin_bit_cast(s4v, tl);
-                split4(dab, th, tl);
-                const s4v dab_hi = __builtin_bit_cast(s4v, th), dab_lo = __builtin_bit_cast(s4v, tl);
-                split4(dba, th, tl);
-                const s4v dba_hi = __builtin_bit_cast(s4v, th), dba_lo = __builtin_bit_cast(s4v, tl);
-
-                // fragments reused below
-                s4v gyT[4], rhf[4], rlf[4];
+                const s4v gyT_w = tr_read(bb + B_GY * ARR + troff + 32 * wv);      // gy[4g+e][16wv + x]
+                // gv^T[j][b]
+                f4v acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mfma16(gyT_w, sc_hi, acc);
+                acc = mfma16(gyT_w, sc_lo, acc);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    gyT[t] = tr_read(bb + B_GY * ARR + troff + 32 * t);   // gy[4g+e][16t + x]
-                    rhf[t] = tr_read(bb + B_RH * ARR + troff + 32 * t);   // Rhat[4g+e][16t + x]
-                    rlf[t] = tr_read(bb + B_RL * ARR + troff + 32 * t);
+                for (int s = 0; s < 2; ++s) {
+                    float t0[4], t1[4];
+                    const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 4 * g) * 4);
+                    const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 16 + 4 * g) * 4);
+                    t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
+                    t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
+                    t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
+                    b8v gh, gl;
+                    split8(t0, t1, gh, gl);
+                    const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
+                    const b8v kh = ld_b8_2x4(p0 + B_KH * ARR, p0 + B_KH * ARR + 32);
+                    const b8v kl = ld_b8_2x4(p0 + B_KL * ARR, p0 + B_KL * ARR + 32);
+                    acc = mfma32(gh, kh, acc);
+                    acc = mfma32(gh, kl, acc);
+                    acc = mfma32(gl, kh, acc);
                 }
-                // this wave's own tiles, read by address (indexing gyT[wv] would be a runtime register index)
-                const s4v gyT_w = tr_read(bb + B_GY * ARR + troff + 32 * wv);
-                const s4v rhf_w = tr_read(bb + B_RH * ARR + troff + 32 * wv);
-                const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
-                const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
-                const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
-                const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
-                const float e16x = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
-                const float e16m8x = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
-
-                // ---- gv for value columns [16wv, 16wv+16):  gv^T[j][b]
                 {
-                    f4v acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = mfma16(gyT_w, sc_hi, acc);
-                    acc = mfma16(gyT_w, sc_lo, acc);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        float t0[4], t1[4];
-                        const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 4 * g) * 4);
-                        const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 16 + 4 * g) * 4);
-                        t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
-                        t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
-                        t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
-                        b8v gh, gl;
-                        split8(t0, t1, gh, gl);
-                        const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
-                        const b8v kh = ld_b8_2x4(p0 + B_KH * ARR, p0 + B_KH * ARR + 32);
-                        const b8v kl = ld_b8_2x4(p0 + B_KL * ARR, p0 + B_KL * ARR + 32);
-                        acc = mfma32(gh, kh, acc);
-                        acc = mfma32(gh, kl, acc);
-                        acc = mfma32(gl, kh, acc);
-                    }
                     const int p = grp * GRP + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
@@ -326,98 +456,14 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
                         io4<bf16_t>::store(ogv + idx, o);
                     }
                 }
-
-                // ---- gr / gk / gw for key rows [16wv, 16wv+16): accumulators [i_local = 4g+q][token x]
-                f4v accr = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float t0[4], t1[4];
-                    b8v hi, lo;
-                    const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q] * e8x; t1[q] = ST[blk][2 * s + 1][q] * e8x; }
-                    split8(t0, t1, hi, lo);
-                    const b8v gyp = ld_b8_2x4(p0 + B_GY * ARR, p0 + B_GY * ARR + 32);
-                    accr = mfma32(hi, gyp, accr);
-                    accr = mfma32(lo, gyp, accr);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
-                    split8(t0, t1, hi, lo);
-                    const b8v vp = ld_b8_2x4(p0 + B_V * ARR, p0 + B_V * ARR + 32);
-                    acck = mfma32(hi, vp, acck);
-                    acck = mfma32(lo, vp, acck);
-                }
-                accr = mfma16(khf, dba_hi, accr);                // sum_b Khat[b][i] dA[a][b]
-                accr = mfma16(khf, dba_lo, accr);
-                accr = mfma16(klf, dba_hi, accr);
-                acck = mfma16(rhf_w, dab_hi, acck);            // sum_a Rhat[a][i] dA[a][b]
-                acck = mfma16(rhf_w, dab_lo, acck);
-                acck = mfma16(rlf_w, dab_hi, acck);
-                {
-                    const int ch = 16 * wv + 4 * g;
-                    const float4 cex4 = *reinterpret_cast<const float4*>(bb + BOFF_CEX + x * FRS + ch * 4);
-                    const float4 lw4 = *reinterpret_cast<const float4*>(bb + BOFF_LW + x * FRS + ch * 4);
-                    const float4 c84 = *reinterpret_cast<const float4*>(bb + BOFF_C8 + ch * 4);
-                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
-                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
-                    const float cexv[4] = {cex4.x, cex4.y, cex4.z, cex4.w}, lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
-                    const float c8v[4] = {c84.x, c84.y, c84.z, c84.w};
-                    const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
-                    const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
-                    float o_gr[4], o_gk[4], o_gw[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float lwc = fmaxf(lwv[q], LW_MIN);              // the decay the block algebra used
-                        const float dq = __expf(cexv[q] - c8v[q]) * accr[q];
-                        const float dk = __expf(c8v[q] - cexv[q] - lwc) * acck[q];
-                        o_gr[q] = fmaf(vg * ue[q], kv[q], dq);
-                        o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
-                        gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
-                        const float bt = kv[q] * dk;
-                        const float dl = rv[q] * dq - bt;
-                        float sfx = dl;                           // inclusive suffix sum over the later tokens of the row
-                        sfx += dpp_mov<DPP_SHL1>(sfx);
-                        sfx += dpp_mov<DPP_SHL2>(sfx);
-                        sfx += dpp_mov<DPP_SHL4>(sfx);
-                        sfx += dpp_mov<DPP_SHL8>(sfx);
-                        const float total = __shfl(sfx, lane & 48);
-                        // d(loss)/d(ew) of the clamped model is d_clamped * X; the true one is d_true * X, so where the
-                        // clamp is active rescale by d_true / d_clamped = e^{lw - lwc} (exactly 1 elsewhere)
-                        o_gw[q] = (Rc[q] + (sfx - dl) - bt) * lwv[q] * __expf(lwv[q] - lwc);
-                        Rc[q] += total;
-                    }
-                    const int p = grp * GRP + blk * BLK + x;
-                    if (p < ntok) {
-                        const int t = a.reverse ? ntok - 1 - p : p;
-                        const long idx = base + (long)t * a.C + ch;
-                        if (a.accumulate) {
-                            float o1[4], o2[4], o3[4];
-                            io4<bf16_t>::load(ogr + idx, o1);
-                            io4<bf16_t>::load(ogk + idx, o2);
-                            io4<bf16_t>::load(ogw + idx, o3);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { o_gr[q] += o1[q]; o_gk[q] += o2[q]; o_gw[q] += o3[q]; }
-                        }
-                        io4<bf16_t>::store(ogr + idx, o_gr);
-                        io4<bf16_t>::store(ogk + idx, o_gk);
-                        io4<bf16_t>::store(ogw + idx, o_gw);
-                    }
-                }
-
-                // ---- G <- E16 (.) G + E8 (.) (Rhat^T gy), in both orientations
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    f4v o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma16(gyT[jt], rhf_w, o);             // [row j_local][col i_local = x]
-                    o = mfma16(gyT[jt], rlf_w, o);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * o[q]);
-                }
+                // ---- G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
+                    const s4v rhf = tr_read(bb + B_RH * ARR + troff + 32 * it);    // Rhat[4g+e][16it + x]
+                    const s4v rlf = tr_read(bb + B_RL * ARR + troff + 32 * it);
                     f4v o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma16(rhf[it], gyT_w, o);             // [row i_local][col j_local = x]
-                    o = mfma16(rlf[it], gyT_w, o);
+                    o = mfma16(rhf, gyT_w, o);                   // [row i_local][col j_local = x]
+                    o = mfma16(rlf, gyT_w, o);
                     const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (16 * it + 4 * g) * 4);
                     const float4 d8 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (16 * it + 4 * g) * 4);
                     GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * o[0]);
@@ -426,28 +472,21 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
                     GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * o[3]);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-
-    if (a.gs) {   // dL/dS0, layout [j][i]
-        bf16_t* const og = reinterpret_cast<bf16_t*>(a.gs) + ((long)b * a.H + h) * HEAD * HEAD;
+        if (a.gs) {   // dL/dS0, layout [j][i]
+            bf16_t* const og = reinterpret_cast<bf16_t*>(a.gs) + ((long)b * a.H + h) * HEAD * HEAD;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const float t4[4] = {GJ[it][0], GJ[it][1], GJ[it][2], GJ[it][3]};
-            io4<bf16_t>::store(og + (long)(16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
+            for (int it = 0; it < 4; ++it) {
+                const float t4[4] = {GJ[it][0], GJ[it][1], GJ[it][2], GJ[it][3]};
+                io4<bf16_t>::store(og + (long)(16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
+            }
         }
-    }
-    if (a.gu) {
-        float s4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s4[q] = row_sum16(gu_acc[q]);
-        if (x == 0) io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.gu) + (long)b * a.C + h * HEAD + 16 * wv + 4 * g, s4);
     }
     if (a.zero_tail && !a.accumulate) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = ntok + (tid >> 4); t < a.T; t += 16) {
-            const long idx = base + (long)t * a.C + 4 * c4;
+        for (int t = ntok + (tid >> 4); t < a.T; t += 32) {
+            const long idx = base + (long)t * a.C + 4 * (tid & 15);
             io4<bf16_t>::store(ogr + idx, z);
             io4<bf16_t>::store(ogk + idx, z);
             io4<bf16_t>::store(ogv + idx, z);
@@ -459,6 +498,7 @@ __global__ __launch_bounds__(256) void chunk_bwd_kernel(const ScanArgs a)
 template <bool W_RAW> hipError_t launch_bwd_variant(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = (size_t)NBLK * BBLK_BYTES;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_bwd_kernel<W_RAW>),
@@ -466,7 +506,7 @@ template <bool W_RAW> hipError_t launch_bwd_variant(const ScanArgs& a, hipStream
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL((chunk_bwd_kernel<W_RAW>), dim3(a.B * a.H), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((chunk_bwd_kernel<W_RAW>), dim3(a.B * a.H), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -474,10 +514,11 @@ template <bool W_RAW> hipError_t launch_bwd_variant(const ScanArgs& a, hipStream
 
 hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
 {
-    ScanArgs sp = a;                       // state pass: same inputs, no outputs, dump group-entry states
-    sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
-    if (!a.ckpt_valid)
+    if (!a.ckpt_valid) {                   // self-contained backward: state pass first (same inputs, no outputs)
+        ScanArgs sp = a;
+        sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
         if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
+    }
     return a.wkind ? launch_bwd_variant<true>(a, st) : launch_bwd_variant<false>(a, st);
 }
 
