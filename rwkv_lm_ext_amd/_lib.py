@@ -54,9 +54,11 @@ def load():
     global _lib
     with _lock:
         if _lib is None:
-            path = _build.LIB_PATH
-            if os.environ.get("RWKV_AMD_NO_BUILD", "0") != "1":
-                path = _build.build()
+            path = os.environ.get("RWKV_AMD_LIB")        # explicit library (A/B experiments); normally unset
+            if not path:
+                path = _build.LIB_PATH
+                if os.environ.get("RWKV_AMD_NO_BUILD", "0") != "1":
+                    path = _build.build()
             if not os.path.exists(path):
                 raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
             lib = ctypes.CDLL(path)

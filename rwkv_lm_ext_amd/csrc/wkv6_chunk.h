@@ -20,7 +20,8 @@ constexpr int OFF_E8 = N_ARR * ARR;                    // float[64]  e^{c_8}
 constexpr int OFF_E16 = OFF_E8 + 256;                  // float[64]  e^{c_16}
 constexpr int OFF_E16M8 = OFF_E16 + 256;               // float[64]  e^{c_16 - c_8}
 constexpr int OFF_COEF = OFF_E16M8 + 256;              // float[16]  sum_i r u k
-constexpr int BLK_BYTES = OFF_COEF + 16 * 4;           // 12352
+constexpr int OFF_SC = OFF_COEF + 16 * 4;              // uint4 [64]  masked scores^T, bf16x4 hi | bf16x4 lo: the B fragment of each lane
+constexpr int BLK_BYTES = OFF_SC + 2 * 64 * 8;
 constexpr float LW_MIN = -9.0f;
 
 __device__ __forceinline__ s4v tr_read(const char* p)

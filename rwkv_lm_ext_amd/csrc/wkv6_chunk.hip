@@ -43,7 +43,8 @@ constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 // STATE_ONLY: no outputs, only the state recurrence (first half of the self-contained backward).
 // With a.ckpt the state at the entry of every 64-token group is dumped (fp32, register order:
 // [wave][tile][lane][4]) for the backward kernel.
-template <bool W_RAW, bool STATE_ONLY>
+// ACC: add into y (from a.y_f32 when given) instead of overwriting -- the reverse half of wkv6_bi.
+template <bool W_RAW, bool STATE_ONLY, bool ACC>
 __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES]
@@ -154,6 +155,37 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 split4(kh, hi, lo);
                 *reinterpret_cast<uint2*>(row + A_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_KL * ARR) = lo;
             }
+            if constexpr (!STATE_ONLY) {
+                // Scores of this block, once for all four consumers: sc[b][a] = sum_i Khat[b][i] Rhat[a][i] from the rows this
+                // wave has just written (LDS operations of one wave execute in order), masked to b < a with the bonus
+                // coefficient on the diagonal, split, and stored as the B fragment each consumer lane needs
+                // (lane: column a = x, k rows b = 4g+q).
+                const int x = lane & 15, g = lane >> 4;
+                // the stores above are uint2 / float typed, the fragment loads bf16x8 typed: without this fence type-based
+                // alias analysis lets the compiler hoist the loads above the stores
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                asm volatile("" ::: "memory");
+                f4v sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int off = x * RSB + (32 * s + 8 * g) * 2;
+                    const b8v kh = ld_b8(bb + A_KH * ARR + off), kl = ld_b8(bb + A_KL * ARR + off);
+                    const b8v rh = ld_b8(bb + A_RH * ARR + off), rl = ld_b8(bb + A_RL * ARR + off);
+                    sc = mfma32(kh, rh, sc);
+                    sc = mfma32(kh, rl, sc);
+                    sc = mfma32(kl, rh, sc);
+                }
+                const float cf = *reinterpret_cast<const float*>(bb + OFF_COEF + x * 4);
+                float scm[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int bt = 4 * g + q;                            // key token; query token = x
+                    scm[q] = bt < x ? sc[q] : (bt == x ? cf : 0.f);
+                }
+                uint2 sh, sl;
+                split4(scm, sh, sl);
+                *reinterpret_cast<uint4*>(bb + OFF_SC + lane * 16) = make_uint4(sh.x, sh.y, sl.x, sl.y);
+            }
         };
 
         if (ngrp > 0) {
@@ -192,33 +224,18 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                     *reinterpret_cast<float4*>(ck + ((wv * 4 + it) * 64 + lane) * 4) =
                         make_float4(St[it][0], St[it][1], St[it][2], St[it][3]);
             }
+            // Rolled on purpose (runtime trip count): a fully unrolled 4-block body was measured no faster and was
+            // miscompiled by hipcc 7.2 (wrong y in the first block of a group).
             const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
                 // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
                 const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);
                 if constexpr (!STATE_ONLY) {
-                    // (1) transposed scores sc[b][a] = sum_i Khat[b][i] Rhat[a][i]; lane: column a = x, rows b = 4g+q
-                    f4v sc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int off = x * RSB + (32 * s + 8 * g) * 2;
-                        const b8v kh = ld_b8(bb + A_KH * ARR + off), kl = ld_b8(bb + A_KL * ARR + off);
-                        const b8v rh = ld_b8(bb + A_RH * ARR + off), rl = ld_b8(bb + A_RL * ARR + off);
-                        sc = mfma32(kh, rh, sc);
-                        sc = mfma32(kh, rl, sc);
-                        sc = mfma32(kl, rh, sc);
-                    }
-                    const float cf = *reinterpret_cast<const float*>(bb + OFF_COEF + x * 4);
-                    float scm[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int bt = 4 * g + q;                        // key token; query token = x
-                        scm[q] = bt < x ? sc[q] : (bt == x ? cf : 0.f);
-                    }
-                    uint2 sh, sl;
-                    split4(scm, sh, sl);
-                    const s4v sc_hi = __builtin_bit_cast(s4v, sh), sc_lo = __builtin_bit_cast(s4v, sl);
+                    // (1) masked transposed scores, prepared by the producer of this block
+                    const uint4 scp = *reinterpret_cast<const uint4*>(bb + OFF_SC + lane * 16);
+                    const s4v sc_hi = __builtin_bit_cast(s4v, make_uint2(scp.x, scp.y));
+                    const s4v sc_lo = __builtin_bit_cast(s4v, make_uint2(scp.z, scp.w));
                     // (2) y^T[j][a] = sum_b V[b][j] sc[b][a]
                     f4v yt = {0.f, 0.f, 0.f, 0.f};
                     yt = mfma16(vf, sc_hi, yt);
@@ -245,18 +262,20 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                     }
                     {   // store: lane holds y[token x][j = 16wv + 4g + q]
                         const int p = grp * GRP + blk * BLK + x;
-                        if (p < ntok) {
-                            const int t = a.reverse ? ntok - 1 - p : p;
-                            const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
-                            float o[4] = {yt[0], yt[1], yt[2], yt[3]};
-                            if (a.accumulate) {
-                                float old[4];
-                                if (a.y_f32) io4<float>::load(a.y_f32 + idx, old);
-                                else io4<bf16_t>::load(gy_ + idx, old);
+                        const bool valid = p < ntok;
+                        const int pc = valid ? p : 0;                    // padding lanes still form a legal address
+                        const int t = a.reverse ? ntok - 1 - pc : pc;
+                        const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
+                        float o[4] = {yt[0], yt[1], yt[2], yt[3]};
+                        if constexpr (ACC) {
+                            float old[4];
+                            if (a.y_f32) io4<float>::load(a.y_f32 + idx, old);
+                            else io4<bf16_t>::load(gy_ + idx, old);
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) o[q] += old[q];
-                            }
-                            if (a.y_f32 && !a.accumulate) io4<float>::store(a.y_f32 + idx, o);
+                            for (int q = 0; q < 4; ++q) o[q] += old[q];
+                        }
+                        if (valid) {
+                            if (!ACC && a.y_f32) io4<float>::store(a.y_f32 + idx, o);
                             else io4<bf16_t>::store(gy_ + idx, o);
                         }
                     }
@@ -288,24 +307,24 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             }
         }
     }
-    if (!STATE_ONLY && a.zero_tail && !a.accumulate) {
+    if (!STATE_ONLY && !ACC && a.zero_tail) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += 32)
             io4<bf16_t>::store(gy_ + base + (long)t * a.C + 4 * (tid & 15), z);
     }
 }
 
-template <bool W_RAW, bool STATE_ONLY> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
+template <bool W_RAW, bool STATE_ONLY, bool ACC> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = 2 * (size_t)GRP_BYTES;
     static bool configured = false;            // per instantiation; the attribute is per function, set once
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY>), dim3(a.B * a.H), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), dim3(a.B * a.H), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -313,13 +332,14 @@ template <bool W_RAW, bool STATE_ONLY> hipError_t launch_fwd_variant(const ScanA
 
 hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st)
 {
-    return a.wkind ? launch_fwd_variant<true, false>(a, st) : launch_fwd_variant<false, false>(a, st);
+    if (a.accumulate) return a.wkind ? launch_fwd_variant<true, false, true>(a, st) : launch_fwd_variant<false, false, true>(a, st);
+    return a.wkind ? launch_fwd_variant<true, false, false>(a, st) : launch_fwd_variant<false, false, false>(a, st);
 }
 
 // state recurrence only, dumping the group-entry states into a.ckpt (first half of the self-contained backward)
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st)
 {
-    return a.wkind ? launch_fwd_variant<true, true>(a, st) : launch_fwd_variant<false, true>(a, st);
+    return a.wkind ? launch_fwd_variant<true, true, false>(a, st) : launch_fwd_variant<false, true, false>(a, st);
 }
 
 size_t chunk_ckpt_floats(int B, int T, int H)
