@@ -10,7 +10,9 @@ per-GPU workload -- the path shards over the batch with no data-path collective 
 reported value is the whole-job rate: N * tokens / max-over-ranks time.  Rank 0 prints ONE JSON line.
 
 Algorithmic bytes: forward reads r,k,v,w and writes y = 10 B per token-channel, backward
-reads r,k,v,w,gy and writes gr,gk,gv,gw = 18 B; 28 B per token-channel for the step.
+reads r,k,v,w,gy and writes gr,gk,gv,gw = 18 B; 28 B per token-channel for the step.  The forward also writes, and
+the backward reads, one fp32 64x64 state checkpoint per 64 tokens (4 B per token-channel each way) -- real traffic
+(reported in roofline.traffic) that is NOT counted in the algorithmic figure.
 """
 import argparse
 import json
@@ -26,6 +28,18 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FWD_BYTES, BWD_BYTES = 10, 18   # per token-channel
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_chunk_final_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot read PMCs itself, so this is the
+    number measured for the headline workload with the committed kernels; None for any other workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_chunk_final_pmc.json")) as f:
+            return int(json.load(f)["kernels"][kernel]["hbm_bytes"])
+    except Exception:
+        return None
 
 
 def synth(B, T, H, device, seed=0):
@@ -168,13 +182,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "io": "bf16", "tokens_per_gpu": tokens, "channels": C,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": name, "io": "bf16",
+                       "math": "split-bf16 (hi+lo) MFMA operands, fp32 accumulate and state",
+                       "tokens_per_gpu": tokens, "channels": C,
                        "parallelism": f"dp{world} (independent batches per GPU, no data-path collective)",
                        "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBPS, 4),
+                         "traffic": measured_traffic("chunk_bwd_kernel" if dom_name == "backward" else "chunk_fwd_kernel")
+                         if args.workload == "wkv6" else None,
                          "algorithmic_bytes_per_launch": units * dom_b, "avg_ms": round(dom_ms, 4)},
             "roofline_step": {"bound": "hbm", "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(step_ach / HBM_PEAK_GBPS, 4),

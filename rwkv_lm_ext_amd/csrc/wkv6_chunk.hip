@@ -214,9 +214,12 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                                   ((long)h * HEAD + 16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
             St[it] = f4v{t4[0], t4[1], t4[2], t4[3]};
         }
-        const int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
+        int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
+            // every ds_read_b64_tr_b16 address of this iteration depends on this statement, which cannot move above the
+            // barrier: the transposed reads are guaranteed to be issued after the producers' writes are visible
+            asm volatile("" : "+v"(troff));
             if (a.ckpt) {
                 float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + GRP - 1) / GRP) + grp) * (HEAD * HEAD);
 #pragma unroll

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 
     // ---- phase-C role
     const int x = lane & 15, g = lane >> 4;
-    const int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
+    int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
     const int ngrp = (ntok + GRP - 1) / GRP;
     if (ngrp > 0) load_group(ngrp - 1);
 
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
             }
             prep_group(grp);
             __syncthreads();
+            asm volatile("" : "+v"(troff));      // pins every transposed LDS read of this iteration below the barrier
             if (grp > 0) load_group(grp - 1);
             const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
 
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             prep_group(grp);
             __syncthreads();
+            asm volatile("" : "+v"(troff));      // pins every transposed LDS read of this iteration below the barrier
             if (grp > 0) load_group(grp - 1);
             const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
             for (int blk = nb - 1; blk >= 0; --blk) {
