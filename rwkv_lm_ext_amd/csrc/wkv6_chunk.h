@@ -24,6 +24,15 @@ constexpr int OFF_SC = OFF_COEF + 16 * 4;              // uint4 [64]  masked sco
 constexpr int BLK_BYTES = OFF_SC + 2 * 64 * 8;
 constexpr float LW_MIN = -9.0f;
 
+// State tiles are 16x16 C-layout MFMA tiles; tile t = 2s + hb, row rho = 4g + q of a tile stands for channel
+//     tile_ch(t) + 8g + q        with   tile_ch(t) = 32 (t >> 1) + 4 (t & 1)
+// (not 16t + rho): with this labelling the 8 values a lane feeds into k-step s of a 16x16x32 MFMA (tiles 2s and
+// 2s+1, rows 4g..4g+3) are the 8 CONTIGUOUS channels 32s + 8g .. +7, so the other operand is a plain 16-byte row
+// read -- conflict-free at the 160-B row stride, unlike the ds_read2_b64 pairs a permuted k order needs.
+__device__ __forceinline__ constexpr int tile_ch(int t) { return 32 * (t >> 1) + 4 * (t & 1); }
+// byte offset (within a bf16 row) of the column chunk lane p supplies to a transposed read of tile t
+__device__ __forceinline__ constexpr int tile_tr(int t) { return 64 * (t >> 1) + 8 * (t & 1); }
+
 __device__ __forceinline__ s4v tr_read(const char* p)
 {   // ds_read_b64_tr_b16: lane x of each 16-lane group receives column x of a 4-row x 16-column block whose
     // row q / columns 4p..4p+3 are addressed by lane 4q+p of the group

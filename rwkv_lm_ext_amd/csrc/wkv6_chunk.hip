@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         }
     } else {
         // ============================== consumer: value columns [16wv, 16wv+16) =========================
-        // lane (x = lane&15, g = lane>>4) holds S[i = 16it + 4g + q][j = 16wv + x] in St[it][q]
+        // lane (x = lane&15, g = lane>>4) holds S[i = tile_ch(it) + 8g + q][j = 16wv + x] in St[it][q]
         const int x = lane & 15, g = lane >> 4;
         f4v St[4];
 #pragma unroll
@@ -211,15 +211,16 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             float t4[4] = {0.f, 0.f, 0.f, 0.f};
             if (a.s0)
                 io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.s0) + (long)b * a.s0_bstride +
-                                  ((long)h * HEAD + 16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
+                                  ((long)h * HEAD + 16 * wv + x) * HEAD + tile_ch(it) + 8 * g, t4);
             St[it] = f4v{t4[0], t4[1], t4[2], t4[3]};
         }
-        int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
+        int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read, natural columns (this wave's V tile)
+        int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
             // every ds_read_b64_tr_b16 address of this iteration depends on this statement, which cannot move above the
             // barrier: the transposed reads are guaranteed to be issued after the producers' writes are visible
-            asm volatile("" : "+v"(troff));
+            asm volatile("" : "+v"(troff), "+v"(trow));
             if (a.ckpt) {
                 float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + GRP - 1) / GRP) + grp) * (HEAD * HEAD);
 #pragma unroll
@@ -243,11 +244,11 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                     f4v yt = {0.f, 0.f, 0.f, 0.f};
                     yt = mfma16(vf, sc_hi, yt);
                     yt = mfma16(vf, sc_lo, yt);
-                    // (3) y^T[j][a] += sum_i (E8 S)[i][j] Rhat[a][i]; k-slot (s,g,e) <-> channel 32s + 16(e>>2) + 4g + (e&3)
+                    // (3) y^T[j][a] += sum_i (E8 S)[i][j] Rhat[a][i]; k-slot (s, g, e) <-> channel 32s + 8g + e
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const float4 m0 = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 4 * g) * 4);
-                        const float4 m1 = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 16 + 4 * g) * 4);
+                        const float4 m0 = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g) * 4);
+                        const float4 m1 = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g + 4) * 4);
                         const float t0[4] = {St[2 * s][0] * m0.x, St[2 * s][1] * m0.y, St[2 * s][2] * m0.z, St[2 * s][3] * m0.w};
                         const float t1[4] = {St[2 * s + 1][0] * m1.x, St[2 * s + 1][1] * m1.y,
                                              St[2 * s + 1][2] * m1.z, St[2 * s + 1][3] * m1.w};
@@ -256,9 +257,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                         split4(t1, h1, l1);
                         const b8v s_hi = __builtin_bit_cast(b8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
                         const b8v s_lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
-                        const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
-                        const b8v zh = ld_b8_2x4(p0 + A_RH * ARR, p0 + A_RH * ARR + 32);
-                        const b8v zl = ld_b8_2x4(p0 + A_RL * ARR, p0 + A_RL * ARR + 32);
+                        const int off = x * RSB + (32 * s + 8 * g) * 2;
+                        const b8v zh = ld_b8(bb + A_RH * ARR + off), zl = ld_b8(bb + A_RL * ARR + off);
                         yt = mfma32(s_hi, zh, yt);
                         yt = mfma32(s_hi, zl, yt);
                         yt = mfma32(s_lo, zh, yt);
@@ -286,13 +286,13 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 // (4) S[it] <- E16 (.) S[it] + E16m8 (.) (Khat^T V)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const s4v kh = tr_read(bb + A_KH * ARR + troff + 32 * it);
-                    const s4v kl = tr_read(bb + A_KL * ARR + troff + 32 * it);
+                    const s4v kh = tr_read(bb + A_KH * ARR + trow + tile_tr(it));
+                    const s4v kl = tr_read(bb + A_KL * ARR + trow + tile_tr(it));
                     f4v o = {0.f, 0.f, 0.f, 0.f};
                     o = mfma16(kh, vf, o);
                     o = mfma16(kl, vf, o);
-                    const float4 d16 = *reinterpret_cast<const float4*>(bb + OFF_E16 + (16 * it + 4 * g) * 4);
-                    const float4 dm = *reinterpret_cast<const float4*>(bb + OFF_E16M8 + (16 * it + 4 * g) * 4);
+                    const float4 d16 = *reinterpret_cast<const float4*>(bb + OFF_E16 + (tile_ch(it) + 8 * g) * 4);
+                    const float4 dm = *reinterpret_cast<const float4*>(bb + OFF_E16M8 + (tile_ch(it) + 8 * g) * 4);
                     St[it][0] = fmaf(d16.x, St[it][0], dm.x * o[0]);
                     St[it][1] = fmaf(d16.y, St[it][1], dm.y * o[1]);
                     St[it][2] = fmaf(d16.z, St[it][2], dm.z * o[2]);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const float t4[4] = {St[it][0], St[it][1], St[it][2], St[it][3]};
-                io4<bf16_t>::store(so + (long)(16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
+                io4<bf16_t>::store(so + (long)(16 * wv + x) * HEAD + tile_ch(it) + 8 * g, t4);
             }
         }
     }

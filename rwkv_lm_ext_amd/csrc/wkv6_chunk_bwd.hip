@@ -202,14 +202,15 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 
     // ---- phase-C role
     const int x = lane & 15, g = lane >> 4;
-    int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);
+    int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);          // transposed read, natural columns (own tile)
+    int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);          // transposed read, tile-labelled columns: + tile_tr(t)
     const int ngrp = (ntok + GRP - 1) / GRP;
     if (ngrp > 0) load_group(ngrp - 1);
 
     if (rowrole) {
         // =============== key rows [16wv, 16wv+16): gr, gk, gw, gu ==========================================
-        // ST[blk][jt][q] = S_entry(blk)[i = 16wv + x][j = 16jt + 4g + q]   (transposed tiles: lane = key row)
-        // GI[jt][q]      = G[i = 16wv + x][j = 16jt + 4g + q]
+        // ST[blk][jt][q] = S_entry(blk)[i = 16wv + x][j = tile_ch(jt) + 8g + q]   (transposed tiles: lane = key row)
+        // GI[jt][q]      = G[i = 16wv + x][j = tile_ch(jt) + 8g + q]
         float ue[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
         f4v ST[4][4], GI[4];
@@ -220,18 +221,23 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             {   // group-entry forward state (dumped in the forward kernel's register order)
                 const float* const ck = a.ckpt + ((long)blockIdx.x * ngmax + grp) * (HEAD * HEAD);
+                // element S[i = 16wv + x][j]: forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), reg i&3
+                const int i_ = 16 * wv + x;
+                const int fit = 2 * (i_ >> 5) + ((i_ >> 2) & 1), fg = (i_ >> 3) & 3, fq = i_ & 3;
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     float t4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        t4[q] = ck[((jt * 4 + wv) * 64 + 16 * (x >> 2) + 4 * g + q) * 4 + (x & 3)];
+                    for (int q = 0; q < 4; ++q) {
+                        const int j_ = tile_ch(jt) + 8 * g + q;
+                        t4[q] = ck[(((j_ >> 4) * 4 + fit) * 64 + 16 * fg + (j_ & 15)) * 4 + fq];
+                    }
                     ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
                 }
             }
             prep_group(grp);
             __syncthreads();
-            asm volatile("" : "+v"(troff));      // pins every transposed LDS read of this iteration below the barrier
+            asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this iteration below the barrier
             if (grp > 0) load_group(grp - 1);
             const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
 
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     const float e16m8 = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) {
-                        const s4v vf = tr_read(bb + B_V * ARR + troff + 32 * jt);
+                        const s4v vf = tr_read(bb + B_V * ARR + trow + tile_tr(jt));     // V[4g+e][tile_ch(jt) + 8(x>>2) + (x&3)]
                         f4v o = {0.f, 0.f, 0.f, 0.f};
                         o = mfma16(vf, khf, o);
                         o = mfma16(vf, klf, o);
@@ -262,12 +268,14 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     const char* const bb = smem + blk * BBLK_BYTES;
                     // dA in both orientations (exact bf16 operands)
                     f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
+                    b8v gyr[2], vr[2];                           // gy / v [token x][32s + 8g .. +7]: also the B operands below
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const int off = x * RSB + (32 * s + 8 * g) * 2;
-                        const b8v gyr = ld_b8(bb + B_GY * ARR + off), vr = ld_b8(bb + B_V * ARR + off);
-                        dA_ab = mfma32(gyr, vr, dA_ab);          // [row a][col b]: lane col b = x, rows a = 4g+q
-                        dA_ba = mfma32(vr, gyr, dA_ba);          // [row b][col a]: lane col a = x, rows b = 4g+q
+                        gyr[s] = ld_b8(bb + B_GY * ARR + off);
+                        vr[s] = ld_b8(bb + B_V * ARR + off);
+                        dA_ab = mfma32(gyr[s], vr[s], dA_ab);    // [row a][col b]: lane col b = x, rows a = 4g+q
+                        dA_ba = mfma32(vr[s], gyr[s], dA_ba);    // [row b][col a]: lane col a = x, rows b = 4g+q
                     }
                     // vg_x = dA[x][x]: held by lane (x, g = x>>2) in register x&3
                     const float vg = __shfl(pick4(dA_ba, x & 3), 16 * (x >> 2) + x);
@@ -297,20 +305,17 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         float t0[4], t1[4];
-                        b8v hi, lo;
-                        const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
+                        b8v hi, lo;                              // k-slot (s, g, e) <-> value channel 32s + 8g + e
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q] * e8x; t1[q] = ST[blk][2 * s + 1][q] * e8x; }
                         split8(t0, t1, hi, lo);
-                        const b8v gyp = ld_b8_2x4(p0 + B_GY * ARR, p0 + B_GY * ARR + 32);
-                        accr = mfma32(hi, gyp, accr);
-                        accr = mfma32(lo, gyp, accr);
+                        accr = mfma32(hi, gyr[s], accr);
+                        accr = mfma32(lo, gyr[s], accr);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
                         split8(t0, t1, hi, lo);
-                        const b8v vp = ld_b8_2x4(p0 + B_V * ARR, p0 + B_V * ARR + 32);
-                        acck = mfma32(hi, vp, acck);
-                        acck = mfma32(lo, vp, acck);
+                        acck = mfma32(hi, vr[s], acck);
+                        acck = mfma32(lo, vr[s], acck);
                     }
                     accr = mfma16(khf, dba_hi, accr);                // sum_b Khat[b][i] dA[a][b]
                     accr = mfma16(khf, dba_lo, accr);
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) {
-                        const s4v gyf = tr_read(bb + B_GY * ARR + troff + 32 * jt);   // gy[4g+e][16jt + x]
+                        const s4v gyf = tr_read(bb + B_GY * ARR + trow + tile_tr(jt)); // gy[4g+e][tile_ch(jt) + 8(x>>2) + (x&3)]
                         f4v o = {0.f, 0.f, 0.f, 0.f};
                         o = mfma16(gyf, rhf_w, o);                   // [row j_local][col i_local = x]
                         o = mfma16(gyf, rlf_w, o);
@@ -387,27 +392,29 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
         }
     } else {
         // =============== value columns [16wv, 16wv+16): scores, gv, gs ======================================
-        // GJ[it][q] = G[i = 16it + 4g + q][j = 16wv + x]
+        // GJ[it][q] = G[i = tile_ch(it) + 8g + q][j = 16wv + x]
         f4v GJ[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) GJ[t] = f4v{0.f, 0.f, 0.f, 0.f};
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             prep_group(grp);
             __syncthreads();
-            asm volatile("" : "+v"(troff));      // pins every transposed LDS read of this iteration below the barrier
+            asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this iteration below the barrier
             if (grp > 0) load_group(grp - 1);
             const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
             for (int blk = nb - 1; blk >= 0; --blk) {
                 const char* const bb = smem + blk * BBLK_BYTES;
                 f4v sc = {0.f, 0.f, 0.f, 0.f};
+                b8v kh[2], kl[2];                                // Khat[token x][32s + 8g .. +7]: also the B operands of gv below
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int off = x * RSB + (32 * s + 8 * g) * 2;
                     const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
-                    const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
-                    sc = mfma32(rh, kh, sc);                     // A[row a][col b]: lane col b = x, rows a = 4g+q
-                    sc = mfma32(rh, kl, sc);
-                    sc = mfma32(rl, kh, sc);
+                    kh[s] = ld_b8(bb + B_KH * ARR + off);
+                    kl[s] = ld_b8(bb + B_KL * ARR + off);
+                    sc = mfma32(rh, kh[s], sc);                  // A[row a][col b]: lane col b = x, rows a = 4g+q
+                    sc = mfma32(rh, kl[s], sc);
+                    sc = mfma32(rl, kh[s], sc);
                 }
                 const float4 cfa = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 16 * g);
                 const float4 cfb = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 64 + 16 * g);
@@ -429,19 +436,16 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     float t0[4], t1[4];
-                    const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 4 * g) * 4);
-                    const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 16 + 4 * g) * 4);
+                    const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g) * 4);
+                    const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
                     t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
                     t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
                     t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
                     b8v gh, gl;
                     split8(t0, t1, gh, gl);
-                    const char* const p0 = bb + x * RSB + (32 * s + 4 * g) * 2;
-                    const b8v kh = ld_b8_2x4(p0 + B_KH * ARR, p0 + B_KH * ARR + 32);
-                    const b8v kl = ld_b8_2x4(p0 + B_KL * ARR, p0 + B_KL * ARR + 32);
-                    acc = mfma32(gh, kh, acc);
-                    acc = mfma32(gh, kl, acc);
-                    acc = mfma32(gl, kh, acc);
+                    acc = mfma32(gh, kh[s], acc);                // k-slot (s, g, e) <-> key channel 32s + 8g + e
+                    acc = mfma32(gh, kl[s], acc);
+                    acc = mfma32(gl, kh[s], acc);
                 }
                 {
                     const int p = grp * GRP + blk * BLK + x;
@@ -461,13 +465,13 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                 // ---- G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const s4v rhf = tr_read(bb + B_RH * ARR + troff + 32 * it);    // Rhat[4g+e][16it + x]
-                    const s4v rlf = tr_read(bb + B_RL * ARR + troff + 32 * it);
+                    const s4v rhf = tr_read(bb + B_RH * ARR + trow + tile_tr(it));  // Rhat[4g+e][tile_ch(it) + 8(x>>2) + (x&3)]
+                    const s4v rlf = tr_read(bb + B_RL * ARR + trow + tile_tr(it));
                     f4v o = {0.f, 0.f, 0.f, 0.f};
                     o = mfma16(rhf, gyT_w, o);                   // [row i_local][col j_local = x]
                     o = mfma16(rlf, gyT_w, o);
-                    const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (16 * it + 4 * g) * 4);
-                    const float4 d8 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (16 * it + 4 * g) * 4);
+                    const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (tile_ch(it) + 8 * g) * 4);
+                    const float4 d8 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (tile_ch(it) + 8 * g) * 4);
                     GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * o[0]);
                     GJ[it][1] = fmaf(d16.y, GJ[it][1], d8.y * o[1]);
                     GJ[it][2] = fmaf(d16.z, GJ[it][2], d8.z * o[2]);
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const float t4[4] = {GJ[it][0], GJ[it][1], GJ[it][2], GJ[it][3]};
-                io4<bf16_t>::store(og + (long)(16 * wv + x) * HEAD + 16 * it + 4 * g, t4);
+                io4<bf16_t>::store(og + (long)(16 * wv + x) * HEAD + tile_ch(it) + 8 * g, t4);
             }
         }
     }
