@@ -1,0 +1,226 @@
+"""Host-side callers of the WKV6 operator: what sits immediately on either side of the hot path in the reference.
+
+Parameter names equal the reference's state_dict keys, so a reference checkpoint loads with ``load_state_dict``.
+
+  reverse helpers      src/model_ext.py:398-419 (create_mask, reverse_x_idx, reverse_x)            SURVEY a12
+  Tmix_x060            src/model.py:376-477 == src/model_encoder_run.py:96-186 (time-mix)          SURVEY a13
+  CMix_x060            src/model.py:616-644 == src/model_encoder_run.py:189-219 (channel-mix)      SURVEY a14
+  Tmix_x060.forward_bi_c   composition C: (WKV(x) + unrev(WKV(rev x))) / 2, src/model_ext.py:421-437    SURVEY a15
+  Tmix_x060.forward_bi_b   composition B: WKV(r,k,v,w,u) + unrev(WKV(r, rev k, rev v, w, u)), src/model_bi.py:325-350  SURVEY a16
+  BiBlock / RwkvEncoder    src/model_encoder_run.py:222-348 (encoder with sentence embedding at the first emb_id)  SURVEY a15
+  pooling / info_nce_loss  src/model_ext.py:1708-1738, 1882-1911                                       SURVEY a17
+
+The WKV call itself is `wkv(B, T, C, H, r, k, v, w, u) -> y` (default: rwkv_lm_ext_amd.wkv.RUN_CUDA_RWKV6, the HIP
+kernels; bf16 on the GPU).  Everything else is plain PyTorch (the GEMMs ride rocBLAS), as in the reference.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ---- a12: padding mask and in-row reversal ---------------------------------------------------------------------
+def create_mask(x, emb_id=1, pad_id=0):
+    """1 for ordinary tokens, 0 for pad and for the embedding marker (src/model_encoder_run.py:7-11)."""
+    return ((x != pad_id) & (x != emb_id)).to(torch.int)
+
+
+def reverse_x_idx(mask, max_len):
+    """Per row: indices that reverse the first sum(mask) positions and keep the rest (src/model_ext.py:410-417).
+    Vectorised (the reference loops over the batch in python)."""
+    n = mask.sum(dim=1, keepdim=True).to(torch.long)                      # [B,1]
+    pos = torch.arange(max_len, device=mask.device).unsqueeze(0)         # [1,T]
+    return torch.where(pos < n, n - 1 - pos, pos)
+
+
+def reverse_x(x, rev_idx):
+    return torch.gather(x, 1, rev_idx.to(x.device).unsqueeze(-1).expand(-1, -1, x.size(-1)))
+
+
+def _default_wkv(B, T, C, H, r, k, v, w, u):
+    from .wkv import RUN_CUDA_RWKV6
+    bf = torch.bfloat16
+    y = RUN_CUDA_RWKV6(B, T, C, H, *(t.to(bf).contiguous() for t in (r, k, v, w, u)))
+    return y.to(r.dtype)
+
+
+class Tmix_x060(nn.Module):
+    """RWKV-6 time-mix around the WKV operator (src/model.py:376-477)."""
+
+    def __init__(self, n_embd, dim_att, head_size=64, head_size_divisor=8, wkv=None):
+        super().__init__()
+        self.n_head = dim_att // head_size
+        self.wkv = wkv or _default_wkv
+        d_mix = 64 if n_embd == 4096 else 32                              # TIME_MIX_EXTRA_DIM
+        d_decay = 128 if n_embd == 4096 else 64                           # TIME_DECAY_EXTRA_DIM
+        z = lambda *s: nn.Parameter(torch.zeros(*s))
+        for n in ("x", "w", "k", "v", "r", "g"):
+            setattr(self, "time_maa_" + n, z(1, 1, n_embd))
+        self.time_maa_w1 = z(n_embd, d_mix * 5)
+        self.time_maa_w2 = z(5, d_mix, n_embd)
+        self.time_decay = z(1, 1, dim_att)
+        self.time_decay_w1 = z(n_embd, d_decay)
+        self.time_decay_w2 = z(d_decay, dim_att)
+        self.time_faaaa = z(self.n_head, head_size)
+        self.receptance = nn.Linear(n_embd, dim_att, bias=False)
+        self.key = nn.Linear(n_embd, dim_att, bias=False)
+        self.value = nn.Linear(n_embd, dim_att, bias=False)
+        self.output = nn.Linear(dim_att, n_embd, bias=False)
+        self.gate = nn.Linear(n_embd, dim_att, bias=False)
+        self.ln_x = nn.GroupNorm(self.n_head, dim_att, eps=1e-5 * head_size_divisor ** 2)
+
+    def jit_func(self, x):
+        """token shift, data-dependent lerp (two low-rank GEMMs), r/k/v/g projections, decay LoRA (src/model.py:435-459)."""
+        B, T, C = x.size()
+        xx = F.pad(x, (0, 0, 1, -1)) - x                                  # nn.ZeroPad2d((0,0,1,-1))
+        xxx = x + xx * self.time_maa_x
+        xxx = torch.tanh(xxx @ self.time_maa_w1).view(B * T, 5, -1).transpose(0, 1)
+        xxx = torch.bmm(xxx, self.time_maa_w2).view(5, B, T, -1)
+        mw, mk, mv, mr, mg = xxx.unbind(dim=0)
+        xw = x + xx * (self.time_maa_w + mw)
+        xk = x + xx * (self.time_maa_k + mk)
+        xv = x + xx * (self.time_maa_v + mv)
+        xr = x + xx * (self.time_maa_r + mr)
+        xg = x + xx * (self.time_maa_g + mg)
+        r = self.receptance(xr)
+        k = self.key(xk)
+        v = self.value(xv)
+        g = F.silu(self.gate(xg))
+        w = self.time_decay + torch.tanh(xw @ self.time_decay_w1) @ self.time_decay_w2
+        return r, k, v, g, w
+
+    def jit_func_2(self, x, g):
+        """per-head GroupNorm, gate, output projection (src/model.py:462-468)."""
+        B, T, C = x.size()
+        x = self.ln_x(x.view(B * T, C)).view(B, T, C)
+        return self.output(x * g)
+
+    def _run(self, r, k, v, w):
+        B, T, C = r.shape
+        return self.wkv(B, T, C, self.n_head, r, k, v, w, self.time_faaaa)
+
+    def forward(self, x):
+        """causal time-mix (src/model.py:470-477)."""
+        r, k, v, g, w = self.jit_func(x)
+        return self.jit_func_2(self._run(r, k, v, w), g)
+
+    def forward_bi_c(self, x, rev_idx, mask=None):
+        """composition C (src/model_ext.py:421-437): reverse the hidden states, project twice, average."""
+        r, k, v, g, w = self.jit_func(x)
+        rr, rk, rv, _, rw = self.jit_func(reverse_x(x, rev_idx))
+        y = self._run(r, k, v, w)
+        ry = reverse_x(self._run(rr, rk, rv, rw), rev_idx)
+        return self.jit_func_2((y + ry) / 2, g)
+
+    def forward_bi_b(self, x, mask=None):
+        """composition B (src/model_bi.py:325-350): only k and v are reversed, outputs are added."""
+        B, T, C = x.size()
+        if mask is None:
+            mask = torch.ones(B, T, device=x.device)
+        rev_idx = reverse_x_idx(mask, T)
+        r, k, v, g, w = self.jit_func(x)
+        y = self._run(r, k, v, w)
+        ry = self._run(r, reverse_x(k, rev_idx), reverse_x(v, rev_idx), w)
+        return self.jit_func_2(y + reverse_x(ry, rev_idx), g)
+
+
+class CMix_x060(nn.Module):
+    """RWKV-6 channel-mix FFN (src/model.py:616-644): squared-ReLU key, sigmoid receptance gate."""
+
+    def __init__(self, n_embd, dim_ffn):
+        super().__init__()
+        self.time_maa_k = nn.Parameter(torch.zeros(1, 1, n_embd))
+        self.time_maa_r = nn.Parameter(torch.zeros(1, 1, n_embd))
+        self.key = nn.Linear(n_embd, dim_ffn, bias=False)
+        self.receptance = nn.Linear(n_embd, n_embd, bias=False)
+        self.value = nn.Linear(dim_ffn, n_embd, bias=False)
+
+    def forward(self, x):
+        xx = F.pad(x, (0, 0, 1, -1)) - x
+        k = torch.relu(self.key(x + xx * self.time_maa_k)) ** 2
+        return torch.sigmoid(self.receptance(x + xx * self.time_maa_r)) * self.value(k)
+
+
+class BiBlock(nn.Module):
+    """src/model_encoder_run.py:222-259 (pre-LN residual block, ln0 on the first layer)."""
+
+    def __init__(self, n_embd, dim_att, dim_ffn, layer_id, wkv=None):
+        super().__init__()
+        self.layer_id = layer_id
+        self.ln1 = nn.LayerNorm(n_embd)
+        self.ln2 = nn.LayerNorm(n_embd)
+        if layer_id == 0:
+            self.ln0 = nn.LayerNorm(n_embd)
+        self.att = Tmix_x060(n_embd, dim_att, wkv=wkv)
+        self.ffn = CMix_x060(n_embd, dim_ffn)
+
+    def forward(self, x, rev_idx, mask):
+        if self.layer_id == 0:
+            x = self.ln0(x)
+        x = x + self.att.forward_bi_c(self.ln1(x), rev_idx, mask)
+        return x + self.ffn(self.ln2(x))
+
+
+class RwkvEncoder(nn.Module):
+    """Bidirectional RWKV-6 encoder (src/model_encoder_run.py:262-348, share_emb, no head_qk, no dropout)."""
+
+    def __init__(self, vocab_size, n_embd, n_layer, dim_att=None, dim_ffn=None, emb_id=1, pad_id=0, wkv=None):
+        super().__init__()
+        self.emb_id, self.pad_id = emb_id, pad_id
+        self.emb = nn.Embedding(vocab_size, n_embd)
+        self.blocks = nn.ModuleList([BiBlock(n_embd, dim_att or n_embd, dim_ffn or 4 * n_embd, i, wkv=wkv)
+                                     for i in range(n_layer)])
+        self.ln_out = nn.LayerNorm(n_embd)
+
+    def forward(self, idx, return_logits=False):
+        B, T = idx.size()
+        mask = create_mask(idx, emb_id=self.emb_id, pad_id=self.pad_id)
+        rev_idx = reverse_x_idx(mask, T)
+        x = self.emb(idx)
+        for block in self.blocks:
+            x = block(x, rev_idx, mask)
+        hidden = self.ln_out(x)
+        logits = torch.matmul(hidden, self.emb.weight.t())
+        return (logits, hidden) if return_logits else logits
+
+    def encode_sentence(self, idx):
+        _, hidden = self.forward(idx, True)
+        position = torch.eq(idx, self.emb_id).int().argmax(-1)
+        return hidden[torch.arange(hidden.size(0)), position]
+
+
+# ---- a17: embedding head ---------------------------------------------------------------------------------------
+def pooling(x, actual_len, pooling_type="weightedmean"):
+    """src/model_ext.py:1708-1738.  actual_len[b] = index of the first emb_id token of row b."""
+    T = x.size(1)
+    if pooling_type == "weightedmean":
+        mask = torch.arange(T, device=x.device) <= actual_len.unsqueeze(1)
+        weights = torch.arange(1, T + 1, device=x.device).unsqueeze(0).float() / actual_len.unsqueeze(1).float()
+        weights = weights * mask.float()
+        x = torch.sum(x * weights.unsqueeze(-1), dim=1) / actual_len.unsqueeze(1).float()
+        return x.bfloat16()
+    if pooling_type == "lasttoken":
+        return x[torch.arange(x.size(0)), actual_len]
+    if pooling_type == "avg":
+        mask = (torch.arange(T, device=x.device).unsqueeze(0) < actual_len.unsqueeze(1)).to(x.dtype)
+        return (torch.sum(x * mask.unsqueeze(-1), dim=1) / actual_len.unsqueeze(1).float()).bfloat16()
+    raise ValueError(pooling_type)
+
+
+def cos_sim(a, b):
+    """sentence_transformers.util.cos_sim: all pairs, [len(a), len(b)]."""
+    return F.normalize(a, p=2, dim=1) @ F.normalize(b, p=2, dim=1).t()
+
+
+def pairwise_cos_sim(a, b):
+    """sentence_transformers.util.pairwise_cos_sim: row i of a with row i of b."""
+    return (F.normalize(a, p=2, dim=1) * F.normalize(b, p=2, dim=1)).sum(-1)
+
+
+def info_nce_loss(query, positive, negative=None, scale=20.0):
+    """In-batch-negative loss of RwkvForSequenceEmbedding.training_step (src/model_ext.py:1897-1911):
+    CE([cos_sim(q, p) * 20 | pairwise_cos_sim(q, n) * 20], arange(bs)); negatives are per rank only."""
+    scores = cos_sim(query, positive) * scale
+    if negative is not None:
+        scores = torch.cat([scores, pairwise_cos_sim(query, negative).unsqueeze(1) * scale], dim=1)
+    labels = torch.arange(scores.shape[0], dtype=torch.long, device=scores.device)
+    return F.cross_entropy(scores, labels)

@@ -239,12 +239,11 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
             __syncthreads();
             asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this iteration below the barrier
             if (grp > 0) load_group(grp - 1);
-            const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
 
             // ---- rebuild the entry states of blocks 1..3:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
 #pragma unroll
             for (int blk = 0; blk < NBLK - 1; ++blk) {
-                if (blk + 1 < nb) {
+                {
                     const char* const bb = smem + blk * BBLK_BYTES;
                     const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
                     const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
@@ -262,125 +261,173 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                 }
             }
 
+            // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
+            //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
+            //      Four independent blocks => many instructions in flight.
+            f4v ackp[NBLK];
+            float at[NBLK][4], vgs[NBLK];
 #pragma unroll
             for (int blk = NBLK - 1; blk >= 0; --blk) {
-                if (blk < nb) {
-                    const char* const bb = smem + blk * BBLK_BYTES;
-                    // dA in both orientations (exact bf16 operands)
-                    f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
-                    b8v gyr[2], vr[2];                           // gy / v [token x][32s + 8g .. +7]: also the B operands below
+                const char* const bb = smem + blk * BBLK_BYTES;
+                f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
+                b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: also the B operand of accr
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int off = x * RSB + (32 * s + 8 * g) * 2;
-                        gyr[s] = ld_b8(bb + B_GY * ARR + off);
-                        vr[s] = ld_b8(bb + B_V * ARR + off);
-                        dA_ab = mfma32(gyr[s], vr[s], dA_ab);    // [row a][col b]: lane col b = x, rows a = 4g+q
-                        dA_ba = mfma32(vr[s], gyr[s], dA_ba);    // [row b][col a]: lane col a = x, rows b = 4g+q
-                    }
-                    // vg_x = dA[x][x]: held by lane (x, g = x>>2) in register x&3
-                    const float vg = __shfl(pick4(dA_ba, x & 3), 16 * (x >> 2) + x);
-                    float dab[4], dba[4];
+                for (int s = 0; s < 2; ++s) {
+                    const int off = x * RSB + (32 * s + 8 * g) * 2;
+                    gyr[s] = ld_b8(bb + B_GY * ARR + off);
+                    const b8v vr = ld_b8(bb + B_V * ARR + off);
+                    dA_ab = mfma32(gyr[s], vr, dA_ab);           // [row a][col b]: lane col b = x, rows a = 4g+q
+                    dA_ba = mfma32(vr, gyr[s], dA_ba);           // [row b][col a]: lane col a = x, rows b = 4g+q
+                }
+                // vg_x = dA[x][x]: held by lane (x, g = x>>2) in register x&3
+                const float vg = __shfl(pick4(dA_ba, x & 3), 16 * (x >> 2) + x);
+                vgs[blk] = vg;
+                float dab[4], dba[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 4 * g + q;
+                    dab[q] = x < o ? dA_ab[q] : 0.f;              // dA[a = o][b = x], strictly lower
+                    dba[q] = o < x ? dA_ba[q] : 0.f;              // dA^T[b = o][a = x], strictly lower
+                }
+                uint2 th, tl;
+                split4(dab, th, tl);
+                const s4v dab_hi = __builtin_bit_cast(s4v, th), dab_lo = __builtin_bit_cast(s4v, tl);
+                split4(dba, th, tl);
+                const s4v dba_hi = __builtin_bit_cast(s4v, th), dba_lo = __builtin_bit_cast(s4v, tl);
+                const s4v rhf_w = tr_read(bb + B_RH * ARR + troff + 32 * wv);      // Rhat[4g+e][16wv + x]
+                const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
+                const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
+                const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
+                const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
+                // gr accumulator [i_local = 4g+q][token x]
+                f4v accr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float t0[4], t1[4];
+                    b8v hi, lo;                                  // k-slot (s, g, e) <-> value channel 32s + 8g + e
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q] * e8x; t1[q] = ST[blk][2 * s + 1][q] * e8x; }
+                    split8(t0, t1, hi, lo);
+                    accr = mfma32(hi, gyr[s], accr);
+                    accr = mfma32(lo, gyr[s], accr);
+                }
+                accr = mfma16(khf, dba_hi, accr);                // sum_b Khat[b][i] dA[a][b]
+                accr = mfma16(khf, dba_lo, accr);
+                accr = mfma16(klf, dba_hi, accr);
+                f4v ak = {0.f, 0.f, 0.f, 0.f};
+                ak = mfma16(rhf_w, dab_hi, ak);                  // sum_a Rhat[a][i] dA[a][b]
+                ak = mfma16(rhf_w, dab_lo, ak);
+                ak = mfma16(rlf_w, dab_hi, ak);
+                ackp[blk] = ak;
+                {   // gr, a_t, gu: lane = token x, channels ch .. ch+3
+                    const int ch = 16 * wv + 4 * g;
+                    const float4 fr4 = *reinterpret_cast<const float4*>(bb + BOFF_FR + x * FRS + ch * 4);
+                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
+                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
+                    const float frv[4] = {fr4.x, fr4.y, fr4.z, fr4.w};
+                    const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                    const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
+                    float o_gr[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int o = 4 * g + q;
-                        dab[q] = x < o ? dA_ab[q] : 0.f;          // dA[a = o][b = x], strictly lower
-                        dba[q] = o < x ? dA_ba[q] : 0.f;          // dA^T[b = o][a = x], strictly lower
+                        const float dq = frv[q] * accr[q];
+                        o_gr[q] = fmaf(vg * ue[q], kv[q], dq);
+                        gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
+                        at[blk][q] = rv[q] * dq;
                     }
-                    uint2 th, tl;
-                    split4(dab, th, tl);
-                    const s4v dab_hi = __builtin_bit_cast(s4v, th), dab_lo = __builtin_bit_cast(s4v, tl);
-                    split4(dba, th, tl);
-                    const s4v dba_hi = __builtin_bit_cast(s4v, th), dba_lo = __builtin_bit_cast(s4v, tl);
-
-                    const s4v rhf_w = tr_read(bb + B_RH * ARR + troff + 32 * wv);      // Rhat[4g+e][16wv + x]
-                    const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
-                    const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
-                    const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
-                    const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
-                    const float e16x = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
-                    const float e16m8x = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
-
-                    // accumulators [i_local = 4g+q][token x]
-                    f4v accr = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
+                    const int p = grp * GRP + blk * BLK + x;
+                    if (p < ntok) {
+                        const int t = a.reverse ? ntok - 1 - p : p;
+                        const long idx = base + (long)t * a.C + ch;
+                        if (a.accumulate) {
+                            float o1[4];
+                            io4<bf16_t>::load(ogr + idx, o1);
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        float t0[4], t1[4];
-                        b8v hi, lo;                              // k-slot (s, g, e) <-> value channel 32s + 8g + e
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q] * e8x; t1[q] = ST[blk][2 * s + 1][q] * e8x; }
-                        split8(t0, t1, hi, lo);
-                        accr = mfma32(hi, gyr[s], accr);
-                        accr = mfma32(lo, gyr[s], accr);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
-                        split8(t0, t1, hi, lo);
-                        acck = mfma32(hi, vr[s], acck);
-                        acck = mfma32(lo, vr[s], acck);
-                    }
-                    accr = mfma16(khf, dba_hi, accr);                // sum_b Khat[b][i] dA[a][b]
-                    accr = mfma16(khf, dba_lo, accr);
-                    accr = mfma16(klf, dba_hi, accr);
-                    acck = mfma16(rhf_w, dab_hi, acck);              // sum_a Rhat[a][i] dA[a][b]
-                    acck = mfma16(rhf_w, dab_lo, acck);
-                    acck = mfma16(rlf_w, dab_hi, acck);
-                    {
-                        const int ch = 16 * wv + 4 * g;
-                        const float4 fr4 = *reinterpret_cast<const float4*>(bb + BOFF_FR + x * FRS + ch * 4);
-                        const float4 fk4 = *reinterpret_cast<const float4*>(bb + BOFF_FK + x * FRS + ch * 4);
-                        const float4 lw4 = *reinterpret_cast<const float4*>(bb + BOFF_LW + x * FRS + ch * 4);
-                        const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
-                        const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
-                        const float frv[4] = {fr4.x, fr4.y, fr4.z, fr4.w}, fkv[4] = {fk4.x, fk4.y, fk4.z, fk4.w};
-                        const float lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
-                        const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
-                        const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
-                        float o_gr[4], o_gk[4], o_gw[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float dq = frv[q] * accr[q];
-                            const float dk = fkv[q] * acck[q];
-                            o_gr[q] = fmaf(vg * ue[q], kv[q], dq);
-                            o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
-                            gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
-                            const float bt = kv[q] * dk;
-                            const float dl = rv[q] * dq - bt;
-                            float sfx = dl;                       // inclusive suffix sum over the later tokens of the row
-                            sfx += dpp_mov<DPP_SHL1>(sfx);
-                            sfx += dpp_mov<DPP_SHL2>(sfx);
-                            sfx += dpp_mov<DPP_SHL4>(sfx);
-                            sfx += dpp_mov<DPP_SHL8>(sfx);
-                            const float total = __shfl(sfx, lane & 48);
-                            o_gw[q] = (Rc[q] + (sfx - dl) - bt) * lwv[q];
-                            Rc[q] += total;
+                            for (int q = 0; q < 4; ++q) o_gr[q] += o1[q];
                         }
-                        const int p = grp * GRP + blk * BLK + x;
-                        if (p < ntok) {
-                            const int t = a.reverse ? ntok - 1 - p : p;
-                            const long idx = base + (long)t * a.C + ch;
-                            if (a.accumulate) {
-                                float o1[4], o2[4], o3[4];
-                                io4<bf16_t>::load(ogr + idx, o1);
-                                io4<bf16_t>::load(ogk + idx, o2);
-                                io4<bf16_t>::load(ogw + idx, o3);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) { o_gr[q] += o1[q]; o_gk[q] += o2[q]; o_gw[q] += o3[q]; }
-                            }
-                            io4<bf16_t>::store(ogr + idx, o_gr);
-                            io4<bf16_t>::store(ogk + idx, o_gk);
-                            io4<bf16_t>::store(ogw + idx, o_gw);
-                        }
-                    }
-                    // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
-                        const s4v gyf = tr_read(bb + B_GY * ARR + trow + tile_tr(jt)); // gy[4g+e][tile_ch(jt) + 8(x>>2) + (x&3)]
-                        f4v o = {0.f, 0.f, 0.f, 0.f};
-                        o = mfma16(gyf, rhf_w, o);                   // [row j_local][col i_local = x]
-                        o = mfma16(gyf, rlf_w, o);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * o[q]);
+                        io4<bf16_t>::store(ogr + idx, o_gr);
                     }
                 }
+            }
+            // ---- chain: only the work that needs G
+#pragma unroll
+            for (int blk = NBLK - 1; blk >= 0; --blk) {
+                const char* const bb = smem + blk * BBLK_BYTES;
+                const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
+                const float e16x = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
+                const float e16m8x = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
+                // (gy^T Rhat) tiles of the G update: independent of G, issued first so they run under the chain's latency
+                f4v Oi[4];
+                {
+                    const s4v rhf_w = tr_read(bb + B_RH * ARR + troff + 32 * wv);  // Rhat[4g+e][16wv + x]
+                    const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {             // [row j_local][col i_local = x]
+                        const s4v gyf = tr_read(bb + B_GY * ARR + trow + tile_tr(jt));
+                        f4v o = {0.f, 0.f, 0.f, 0.f};
+                        o = mfma16(gyf, rhf_w, o);
+                        o = mfma16(gyf, rlf_w, o);
+                        Oi[jt] = o;
+                    }
+                }
+                f4v acck = ackp[blk];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const b8v vr = ld_b8(bb + B_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
+                    float t0[4], t1[4];
+                    b8v hi, lo;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
+                    split8(t0, t1, hi, lo);
+                    acck = mfma32(hi, vr, acck);
+                    acck = mfma32(lo, vr, acck);
+                }
+                {
+                    const int ch = 16 * wv + 4 * g;
+                    const float4 fk4 = *reinterpret_cast<const float4*>(bb + BOFF_FK + x * FRS + ch * 4);
+                    const float4 lw4 = *reinterpret_cast<const float4*>(bb + BOFF_LW + x * FRS + ch * 4);
+                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
+                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
+                    const float fkv[4] = {fk4.x, fk4.y, fk4.z, fk4.w}, lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
+                    const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                    const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
+                    const float vg = vgs[blk];
+                    float o_gk[4], o_gw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dk = fkv[q] * acck[q];
+                        o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
+                        const float bt = kv[q] * dk;
+                        const float dl = at[blk][q] - bt;
+                        float sfx = dl;                           // inclusive suffix sum over the later tokens of the row
+                        sfx += dpp_mov<DPP_SHL1>(sfx);
+                        sfx += dpp_mov<DPP_SHL2>(sfx);
+                        sfx += dpp_mov<DPP_SHL4>(sfx);
+                        sfx += dpp_mov<DPP_SHL8>(sfx);
+                        const float total = __shfl(sfx, lane & 48);
+                        o_gw[q] = (Rc[q] + (sfx - dl) - bt) * lwv[q];
+                        Rc[q] += total;
+                    }
+                    const int p = grp * GRP + blk * BLK + x;
+                    if (p < ntok) {
+                        const int t = a.reverse ? ntok - 1 - p : p;
+                        const long idx = base + (long)t * a.C + ch;
+                        if (a.accumulate) {
+                            float o2[4], o3[4];
+                            io4<bf16_t>::load(ogk + idx, o2);
+                            io4<bf16_t>::load(ogw + idx, o3);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { o_gk[q] += o2[q]; o_gw[q] += o3[q]; }
+                        }
+                        io4<bf16_t>::store(ogk + idx, o_gk);
+                        io4<bf16_t>::store(ogw + idx, o_gw);
+                    }
+                }
+                // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * Oi[jt][q]);
             }
             __syncthreads();
         }
@@ -401,40 +448,71 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
             __syncthreads();
             asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this iteration below the barrier
             if (grp > 0) load_group(grp - 1);
-            const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
-            for (int blk = nb - 1; blk >= 0; --blk) {
+            // ---- pre-phase: everything that does not depend on G, stage-major over the 4 blocks so that many
+            //      independent LDS reads / MFMAs are in flight (blocks past the end of the sequence are neutral)
+            s4v gyT_w[NBLK], sc_hi[NBLK], sc_lo[NBLK];
+            f4v accp[NBLK], Og[NBLK][4];
+            {
+                f4v sc[NBLK];
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) {
+                    const char* const bb = smem + blk * BBLK_BYTES;
+                    sc[blk] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int off = x * RSB + (32 * s + 8 * g) * 2;
+                        const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
+                        const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
+                        sc[blk] = mfma32(rh, kh, sc[blk]);        // A[row a][col b]: lane col b = x, rows a = 4g+q
+                        sc[blk] = mfma32(rh, kl, sc[blk]);
+                        sc[blk] = mfma32(rl, kh, sc[blk]);
+                    }
+                    gyT_w[blk] = tr_read(bb + B_GY * ARR + troff + 32 * wv);      // gy[4g+e][16wv + x]
+                }
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) {
+                    const char* const bb = smem + blk * BBLK_BYTES;
+                    const float4 cfa = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 16 * g);
+                    const float4 cfb = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 64 + 16 * g);
+                    const float cf[4] = {cfa.x + cfb.x, cfa.y + cfb.y, cfa.z + cfb.z, cfa.w + cfb.w};
+                    float scm[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int o = 4 * g + q;                  // query token a; key token b = x
+                        scm[q] = x < o ? sc[blk][q] : (x == o ? cf[q] : 0.f);
+                    }
+                    uint2 th, tl;
+                    split4(scm, th, tl);
+                    sc_hi[blk] = __builtin_bit_cast(s4v, th);
+                    sc_lo[blk] = __builtin_bit_cast(s4v, tl);
+                }
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) {
+                    const char* const bb = smem + blk * BBLK_BYTES;
+                    f4v acc = {0.f, 0.f, 0.f, 0.f};               // gv^T[j][b], first part: sum_a gy[a][j] A[a][b]
+                    acc = mfma16(gyT_w[blk], sc_hi[blk], acc);
+                    acc = mfma16(gyT_w[blk], sc_lo[blk], acc);
+                    accp[blk] = acc;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {              // (Rhat^T gy) tile: [row i_local][col j_local = x]
+                        const s4v rhf = tr_read(bb + B_RH * ARR + trow + tile_tr(it));
+                        const s4v rlf = tr_read(bb + B_RL * ARR + trow + tile_tr(it));
+                        f4v o = {0.f, 0.f, 0.f, 0.f};
+                        o = mfma16(rhf, gyT_w[blk], o);
+                        o = mfma16(rlf, gyT_w[blk], o);
+                        Og[blk][it] = o;
+                    }
+                }
+            }
+            // ---- chain: only the work that needs G
+#pragma unroll
+            for (int blk = NBLK - 1; blk >= 0; --blk) {
                 const char* const bb = smem + blk * BBLK_BYTES;
-                f4v sc = {0.f, 0.f, 0.f, 0.f};
-                b8v kh[2], kl[2];                                // Khat[token x][32s + 8g .. +7]: also the B operands of gv below
+                f4v acc = accp[blk];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int off = x * RSB + (32 * s + 8 * g) * 2;
-                    const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
-                    kh[s] = ld_b8(bb + B_KH * ARR + off);
-                    kl[s] = ld_b8(bb + B_KL * ARR + off);
-                    sc = mfma32(rh, kh[s], sc);                  // A[row a][col b]: lane col b = x, rows a = 4g+q
-                    sc = mfma32(rh, kl[s], sc);
-                    sc = mfma32(rl, kh[s], sc);
-                }
-                const float4 cfa = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 16 * g);
-                const float4 cfb = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 64 + 16 * g);
-                const float cf[4] = {cfa.x + cfb.x, cfa.y + cfb.y, cfa.z + cfb.z, cfa.w + cfb.w};
-                float scm[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int o = 4 * g + q;                      // query token a; key token b = x
-                    scm[q] = x < o ? sc[q] : (x == o ? cf[q] : 0.f);
-                }
-                uint2 th, tl;
-                split4(scm, th, tl);
-                const s4v sc_hi = __builtin_bit_cast(s4v, th), sc_lo = __builtin_bit_cast(s4v, tl);
-                const s4v gyT_w = tr_read(bb + B_GY * ARR + troff + 32 * wv);      // gy[4g+e][16wv + x]
-                // gv^T[j][b]
-                f4v acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mfma16(gyT_w, sc_hi, acc);
-                acc = mfma16(gyT_w, sc_lo, acc);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                    const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
                     float t0[4], t1[4];
                     const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g) * 4);
                     const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
@@ -443,9 +521,9 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
                     b8v gh, gl;
                     split8(t0, t1, gh, gl);
-                    acc = mfma32(gh, kh[s], acc);                // k-slot (s, g, e) <-> key channel 32s + 8g + e
-                    acc = mfma32(gh, kl[s], acc);
-                    acc = mfma32(gl, kh[s], acc);
+                    acc = mfma32(gh, kh, acc);                   // k-slot (s, g, e) <-> key channel 32s + 8g + e
+                    acc = mfma32(gh, kl, acc);
+                    acc = mfma32(gl, kh, acc);
                 }
                 {
                     const int p = grp * GRP + blk * BLK + x;
@@ -465,17 +543,12 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                 // ---- G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const s4v rhf = tr_read(bb + B_RH * ARR + trow + tile_tr(it));  // Rhat[4g+e][tile_ch(it) + 8(x>>2) + (x&3)]
-                    const s4v rlf = tr_read(bb + B_RL * ARR + trow + tile_tr(it));
-                    f4v o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma16(rhf, gyT_w, o);                   // [row i_local][col j_local = x]
-                    o = mfma16(rlf, gyT_w, o);
                     const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (tile_ch(it) + 8 * g) * 4);
                     const float4 d8 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (tile_ch(it) + 8 * g) * 4);
-                    GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * o[0]);
-                    GJ[it][1] = fmaf(d16.y, GJ[it][1], d8.y * o[1]);
-                    GJ[it][2] = fmaf(d16.z, GJ[it][2], d8.z * o[2]);
-                    GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * o[3]);
+                    GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * Og[blk][it][0]);
+                    GJ[it][1] = fmaf(d16.y, GJ[it][1], d8.y * Og[blk][it][1]);
+                    GJ[it][2] = fmaf(d16.z, GJ[it][2], d8.z * Og[blk][it][2]);
+                    GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * Og[blk][it][3]);
                 }
             }
             __syncthreads();

@@ -1,0 +1,128 @@
+"""Callers of the WKV6 operator on CPU: the glue around the op in fp32, with the CPU oracle
+standing in for the GPU kernels, against vectors captured from the reference's own modules
+(oracle/gen_golden_callers.py -> tests/golden/callers.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, max_norm_err
+from oracle import caller_weights as cw
+from rwkv_lm_ext_amd import callers
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return {k: torch.from_numpy(v) for k, v in load_golden("callers").items()}
+
+
+@pytest.fixture(scope="module")
+def oracle_wkv(oracle):
+    def wkv(B, T, C, H, r, k, v, w, u):
+        f = lambda t: t.detach().float().numpy()
+        return torch.from_numpy(oracle.forward(f(r), f(k), f(v), f(w), f(u)))
+    return wkv
+
+
+def test_reversal_helpers_match_reference_semantics():
+    idx = torch.tensor([[5, 6, 7, 1, 0, 0], [9, 8, 1, 0, 0, 0], [4, 4, 4, 4, 4, 1]])
+    m = callers.create_mask(idx)
+    assert m.tolist() == [[1, 1, 1, 0, 0, 0], [1, 1, 0, 0, 0, 0], [1, 1, 1, 1, 1, 0]] and m.dtype == torch.int
+    rev = callers.reverse_x_idx(m, 6)
+    # reference: cat([arange(0, n).flip(0), arange(n, T)])  (src/model_ext.py:410-417)
+    want = [torch.cat([torch.arange(0, int(n)).flip(0), torch.arange(int(n), 6)]).tolist() for n in m.sum(1)]
+    assert rev.tolist() == want
+    x = torch.arange(3 * 6 * 2).float().view(3, 6, 2)
+    assert torch.equal(callers.reverse_x(callers.reverse_x(x, rev), rev), x)          # an involution
+
+
+def test_time_mix_matches_reference_module(gold, oracle_wkv):
+    tm = callers.Tmix_x060(cw.N_EMBD, cw.DIM_ATT, wkv=oracle_wkv)
+    tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
+    with torch.no_grad():
+        r, k, v, g, w = tm.jit_func(gold["x"])
+        for n, t in zip("rkvgw", (r, k, v, g, w)):
+            assert max_norm_err(t, gold[n]) <= TOL, n
+        y = tm._run(r, k, v, w)
+        assert max_norm_err(y, gold["y"]) <= TOL
+        assert max_norm_err(tm.jit_func_2(y, g), gold["out"]) <= TOL
+        assert max_norm_err(tm(gold["x"]), gold["out"]) <= TOL
+        out_bi = tm.forward_bi_c(gold["x"], gold["rev_idx"], gold["mask"])
+        assert max_norm_err(out_bi, gold["out_bi"]) <= TOL                              # composition C
+        assert torch.equal(callers.reverse_x_idx(gold["mask"], gold["x"].shape[1]), gold["rev_idx"])
+
+
+def test_channel_mix_matches_reference_module(gold):
+    cm = callers.CMix_x060(cw.N_EMBD, cw.DIM_FFN)
+    cm.load_state_dict(cw.cmix_weights(torch.Generator().manual_seed(12)), strict=True)
+    with torch.no_grad():
+        assert max_norm_err(cm(gold["x"]), gold["cm_out"]) <= TOL
+
+
+def test_encoder_matches_reference_module(gold, oracle_wkv):
+    enc = callers.RwkvEncoder(cw.VOCAB, cw.N_EMBD, cw.N_LAYER, cw.DIM_ATT, cw.DIM_FFN, wkv=oracle_wkv)
+    enc.load_state_dict(cw.encoder_weights(), strict=True)
+    with torch.no_grad():
+        logits, hidden = enc(gold["idx"], True)
+        assert max_norm_err(hidden, gold["hidden"]) <= 1e-4
+        assert max_norm_err(logits, gold["logits"]) <= 1e-4
+        assert max_norm_err(enc.encode_sentence(gold["idx"]), gold["sent"]) <= 1e-4
+
+
+def test_composition_b_is_wkv_plus_unreversed_wkv_of_reversed_kv(gold, oracle, oracle_wkv):
+    """src/model_bi.py:325-350 is not importable (Lightning); pinned by composing the oracle by hand on the r,k,v,w the
+    module produces: y = WKV(r,k,v,w,u) + unrev(WKV(r, rev k, rev v, w, u)), reversal over the unmasked prefix."""
+    tm = callers.Tmix_x060(cw.N_EMBD, cw.DIM_ATT, wkv=oracle_wkv)
+    tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
+    x, mask = gold["x"], gold["mask"]
+    with torch.no_grad():
+        got = tm.forward_bi_b(x, mask)
+        r, k, v, g, w = (t.numpy() for t in tm.jit_func(x))
+        u = tm.time_faaaa.detach().numpy()
+        kr, vr = k.copy(), v.copy()
+        for b, n in enumerate(mask.sum(1).tolist()):
+            kr[b, :n] = k[b, :n][::-1]
+            vr[b, :n] = v[b, :n][::-1]
+        y2 = oracle.forward(r, kr, vr, w, u)
+        for b, n in enumerate(mask.sum(1).tolist()):
+            y2[b, :n] = y2[b, :n][::-1].copy()
+        want = tm.jit_func_2(torch.from_numpy(oracle.forward(r, k, v, w, u) + y2), torch.from_numpy(g))
+    assert max_norm_err(got, want) <= TOL
+    with torch.no_grad():                 # no mask => the whole row is reversed (the LM path, model_bi.py:327-329)
+        full = tm.forward_bi_b(x)
+        ones = tm.forward_bi_b(x, torch.ones(2, x.shape[1], dtype=torch.int))
+    assert max_norm_err(full, ones) == 0
+
+
+def test_pooling_known_answers():
+    x = torch.arange(2 * 4 * 2, dtype=torch.float32).view(2, 4, 2)        # x[b,t,:] = [8b+2t, 8b+2t+1]
+    L = torch.tensor([2, 3])
+    # weightedmean: sum_{t<=L} x_t (t+1)/L / L   (src/model_ext.py:1709-1721)
+    wm = callers.pooling(x, L, "weightedmean").float()
+    b0 = (x[0, 0] * 1 / 2 + x[0, 1] * 2 / 2 + x[0, 2] * 3 / 2) / 2
+    b1 = (x[1, 0] * 1 / 3 + x[1, 1] * 2 / 3 + x[1, 2] * 3 / 3 + x[1, 3] * 4 / 3) / 3
+    assert torch.allclose(wm, torch.stack([b0, b1]).bfloat16().float())
+    assert wm.dtype == torch.float32 and callers.pooling(x, L, "weightedmean").dtype == torch.bfloat16
+    assert torch.equal(callers.pooling(x, L, "lasttoken"), torch.stack([x[0, 2], x[1, 3]]))
+    avg = callers.pooling(x, L, "avg").float()
+    assert torch.allclose(avg, torch.stack([x[0, :2].sum(0) / 2, x[1, :3].sum(0) / 3]).bfloat16().float())
+
+
+def test_info_nce_known_answer():
+    """2x2 hand example: q = p (perfect positives), one orthogonal negative each."""
+    q = torch.tensor([[1.0, 0.0], [0.0, 2.0]])
+    p = torch.tensor([[3.0, 0.0], [0.0, 1.0]])
+    n = torch.tensor([[0.0, 5.0], [4.0, 0.0]])
+    # scores*20: rows [20, 0 | 0], [0, 20 | 0]  -> CE = log(e^20 + 2) - 20 for both rows
+    want = float(np.log(np.exp(20.0) + 2.0) - 20.0)
+    assert abs(float(callers.info_nce_loss(q, p, n)) - want) < 1e-6
+    want2 = float(np.log(np.exp(20.0) + 1.0) - 20.0)
+    assert abs(float(callers.info_nce_loss(q, p)) - want2) < 1e-6
+    # general case against the explicit formula
+    g = torch.Generator().manual_seed(3)
+    q, p, n = (torch.randn(5, 8, generator=g) for _ in range(3))
+    cos = lambda a, b: (a / a.norm(dim=1, keepdim=True)) @ (b / b.norm(dim=1, keepdim=True)).t()
+    s = torch.cat([cos(q, p) * 20, torch.diagonal(cos(q, n)).unsqueeze(1) * 20], 1)
+    want = torch.nn.functional.cross_entropy(s, torch.arange(5))
+    assert torch.allclose(callers.info_nce_loss(q, p, n), want, atol=1e-6)
