@@ -67,6 +67,16 @@ int wkv6infctx_cuda_backward(int B, int T, int C, int H, const void* r, const vo
                              const void* w, const void* u, const void* s, const void* gy, void* gr,
                              void* gk, void* gv, void* gw, void* gu, void* gs, void* stream);
 
+/* ---- rwkv6 (stateful forward-only inference): replaces cuda_forward_bf16 / cuda_forward_fp32 of
+ * cuda/rwkv6_op.cpp:8-10 (cuda/rwkv6.cu:8-87).  `w` is the fp32 DECAY exp(-exp(w_raw)) (src/model_run.py:64),
+ * `state` is fp32 [B,H,N,N] (value-major, like s above; [H,N,N] for B = 1 as the reference uses it) and is updated
+ * in place.  The reference indexes the state without the batch (`wrong if B > 1`, cuda/rwkv6.cu:17); here every
+ * batch row has its own state.  (The fp16 flavour of the reference is not provided.) */
+int rwkv6_cuda_forward_bf16(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,
+                            const float* w, const void* u, void* y, void* stream);
+int rwkv6_cuda_forward_fp32(int B, int T, int C, int H, float* state, const float* r, const float* k, const float* v,
+                            const float* w, const float* u, float* y, void* stream);
+
 /* ---- extended entry points -------------------------------------------------------------------------
  * flags (OR together): */
 enum {

@@ -68,10 +68,12 @@ class Tmix_x060(nn.Module):
         self.gate = nn.Linear(n_embd, dim_att, bias=False)
         self.ln_x = nn.GroupNorm(self.n_head, dim_att, eps=1e-5 * head_size_divisor ** 2)
 
-    def jit_func(self, x):
-        """token shift, data-dependent lerp (two low-rank GEMMs), r/k/v/g projections, decay LoRA (src/model.py:435-459)."""
+    def jit_func(self, x, shifted=None):
+        """token shift, data-dependent lerp (two low-rank GEMMs), r/k/v/g projections, decay LoRA (src/model.py:435-459).
+        `shifted`: x delayed by one token; default zero-padded (nn.ZeroPad2d((0,0,1,-1))), the infctx path passes the
+        previous chunk's last token in front (src/model.py:740-741)."""
         B, T, C = x.size()
-        xx = F.pad(x, (0, 0, 1, -1)) - x                                  # nn.ZeroPad2d((0,0,1,-1))
+        xx = (F.pad(x, (0, 0, 1, -1)) if shifted is None else shifted) - x
         xxx = x + xx * self.time_maa_x
         xxx = torch.tanh(xxx @ self.time_maa_w1).view(B * T, 5, -1).transpose(0, 1)
         xxx = torch.bmm(xxx, self.time_maa_w2).view(5, B, T, -1)

@@ -280,6 +280,30 @@ int wkv6infctx_cuda_backward(int B, int T, int C, int H, const void* r, const vo
                             WKV6_W_RAW | WKV6_S0_PER_BATCH, stream);
 }
 
+static int rwkv6_infer(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,
+                       const float* w, const void* u, void* y, bool f32, void* stream)
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!state || !r || !k || !v || !w || !u || !y) return WKV6_ENULL;
+    ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, 0);
+    a.wkind = 2;                                  // w is the decay itself
+    a.state_f32 = 1;
+    a.s0 = state; a.s_out = state;
+    a.s0_bstride = (long)H * HEAD * HEAD;
+    a.y = y;
+    return to_rc(launch_scan_fwd(a, f32, (hipStream_t)stream));
+}
+int rwkv6_cuda_forward_bf16(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,
+                            const float* w, const void* u, void* y, void* stream)
+{
+    return rwkv6_infer(B, T, C, H, state, r, k, v, w, u, y, false, stream);
+}
+int rwkv6_cuda_forward_fp32(int B, int T, int C, int H, float* state, const float* r, const float* k, const float* v,
+                            const float* w, const float* u, float* y, void* stream)
+{
+    return rwkv6_infer(B, T, C, H, state, r, k, v, w, u, y, true, stream);
+}
+
 int wkv6_selftest(void* stream)
 {
     int* d = nullptr;

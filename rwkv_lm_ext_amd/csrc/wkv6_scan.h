@@ -24,8 +24,9 @@ namespace wkv6 {
 
 struct ScanArgs {
     int B, T, C, H;
-    const void *r, *k, *v, *w, *u;   // w: float ew = -exp(w) when wkind == 0, else raw w in the I/O type
-    int wkind;
+    const void *r, *k, *v, *w, *u;   // w: float ew = -exp(w) when wkind == 0, raw w in the I/O type when 1,
+    int wkind;                        //    float decay d = exp(-exp(w)) when 2 (inference kernel, cuda/rwkv6.cu:38)
+    int state_f32;                    // s0 / s_out are fp32 regardless of the I/O type (cuda/rwkv6.cu:8)
     const void* s0;                   // initial state [.., H, N(j), N(i)] in the I/O type, or null (zero)
     long s0_bstride;                  // elements between batch entries of s0 (0: shared over the batch)
     void* s_out;                      // final state [B,H,N,N] in the I/O type, or null   (forward only)

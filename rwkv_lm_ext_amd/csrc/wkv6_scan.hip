@@ -76,8 +76,8 @@ __device__ __forceinline__ void load_ew(const ScanArgs& a, long idx, bool valid,
 #pragma unroll
     for (int c = 0; c < CPT; ++c) ew[c] = 0.f;
     if (!valid) return;
-    if (a.wkind == 0) {
-        lds_load<CPT>(reinterpret_cast<const float*>(a.w) + idx, ew);   // plain (global) vector load
+    if (a.wkind != 1) {
+        lds_load<CPT>(reinterpret_cast<const float*>(a.w) + idx, ew);   // plain (global) vector load (ew, or d when wkind == 2)
     } else {
         float w[CPT];
         ion<T, CPT>::load(reinterpret_cast<const T*>(a.w) + idx, w);
@@ -125,9 +125,11 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanArgs a)
 #pragma unroll
     for (int jj = 0; jj < JR; ++jj) {
         float t4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.s0)
-            io4<T>::load(reinterpret_cast<const T*>(a.s0) + (long)b * a.s0_bstride +
-                         ((long)h * HEAD + j0 + jj) * HEAD + i0, t4);
+        if (a.s0) {
+            const long so_ = (long)b * a.s0_bstride + ((long)h * HEAD + j0 + jj) * HEAD + i0;
+            if (a.state_f32) io4<float>::load(reinterpret_cast<const float*>(a.s0) + so_, t4);
+            else io4<T>::load(reinterpret_cast<const T*>(a.s0) + so_, t4);
+        }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) S[ii][jj] = t4[ii];
     }
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanArgs a)
         float part = 0.f;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            d[c] = __expf(pew[c]);
+            d[c] = a.wkind == 2 ? pew[c] : __expf(pew[c]);
             part = fmaf(pr[c] * uu[c], pk[c], part);
         }
         lds_store<CPT>(ib_, pr);
@@ -226,11 +228,12 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanArgs a)
         }
     }
     if (a.s_out) {
-        T* const so = reinterpret_cast<T*>(a.s_out) + ((long)b * a.H + h) * HEAD * HEAD;
+        const long so_ = ((long)b * a.H + h) * HEAD * HEAD;
 #pragma unroll
         for (int jj = 0; jj < JR; ++jj) {
             const float t4[4] = {S[0][jj], S[1][jj], S[2][jj], S[3][jj]};
-            io4<T>::store(so + (long)(j0 + jj) * HEAD + i0, t4);
+            if (a.state_f32) io4<float>::store(reinterpret_cast<float*>(a.s_out) + so_ + (long)(j0 + jj) * HEAD + i0, t4);
+            else io4<T>::store(reinterpret_cast<T*>(a.s_out) + so_ + (long)(j0 + jj) * HEAD + i0, t4);
         }
     }
     if (a.zero_tail && !a.accumulate) {

@@ -161,3 +161,29 @@ def select_for_train_type(train_type=None):
     if tt == "states":
         return RUN_CUDA_RWKV6_STATE
     return RUN_CUDA_RWKV6
+
+
+class RWKV_6(torch.autograd.Function):
+    """Stateful forward-only WKV for inference (src/model_run.py:49-73): fp32 state [H,N,N] (B = 1) or [B,H,N,N],
+    updated in place and returned; w is the raw decay parameter."""
+
+    @staticmethod
+    def forward(ctx, B, T, C, H, state, r, k, v, w, u):
+        with torch.no_grad():
+            assert HEAD_SIZE == C // H
+            assert state.dtype == torch.float32
+            for t in (r, k, v, w, u):
+                assert t.is_contiguous()
+            eew = torch.exp(-torch.exp(w.float())).contiguous()
+            y = torch.empty((B, T, C), device=w.device, dtype=r.dtype)
+            if r.dtype == torch.bfloat16:
+                wkv6_op.rwkv6.forward_bf16(B, T, C, H, state, r, k, v, eew, u, y)
+            elif r.dtype == torch.float32:
+                wkv6_op.rwkv6.forward_fp32(B, T, C, H, state, r, k, v, eew, u, y)
+            else:
+                wkv6_op.rwkv6.forward_fp16(B, T, C, H, state, r, k, v, eew, u, y)
+            return y, state
+
+
+def RUN_RWKV_6(B, T, C, H, state, r, k, v, w, u):
+    return RWKV_6.apply(B, T, C, H, state, r, k, v, w, u)

@@ -153,6 +153,36 @@ class _Wkv6Infctx(_Wkv6State):
     _name = "wkv6infctx"
 
 
+class _Rwkv6:
+    """Stand-in for `load(name="rwkv6", ...)` (src/model_run.py:46-47): stateful forward-only kernel for inference.
+    forward_bf16 / forward_fp32 (B,T,C,H, state[f32], r,k,v, eew[f32 decay], u, y); state updated in place."""
+
+    @staticmethod
+    def _call(B, T, C, H, state, r, k, v, w, u, y, io):
+        btc = (B, T, C)
+        sshape = None if state.numel() == B * H * HEAD_SIZE * HEAD_SIZE else (-1,)
+        dev = _check_tensors(B, T, C, H, dict(state=(state, sshape, torch.float32), r=(r, btc, io), k=(k, btc, io),
+                                              v=(v, btc, io), w=(w, btc, torch.float32), u=(u, None, io), y=(y, btc, io)),
+                             dtype=io)
+        fn = _lib.load().rwkv6_cuda_forward_bf16 if io == torch.bfloat16 else _lib.load().rwkv6_cuda_forward_fp32
+        with torch.cuda.device(dev):
+            rc = fn(B, T, C, H, _ptr(state), _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(y), _stream_ptr())
+        _lib.check(rc, "rwkv6 forward")
+
+    @staticmethod
+    def forward_bf16(B, T, C, H, state, r, k, v, w, u, y):
+        _Rwkv6._call(B, T, C, H, state, r, k, v, w, u, y, torch.bfloat16)
+
+    @staticmethod
+    def forward_fp32(B, T, C, H, state, r, k, v, w, u, y):
+        _Rwkv6._call(B, T, C, H, state, r, k, v, w, u, y, torch.float32)
+
+    @staticmethod
+    def forward_fp16(*args):
+        raise RuntimeError("rwkv6.forward_fp16 is not provided by the MI355X build (bf16 and fp32 are)")
+
+
+rwkv6 = _Rwkv6
 wkv6_cuda = _Wkv6
 wkv6_bi_cuda = _Wkv6Bi
 wkv6state_cuda = _Wkv6State

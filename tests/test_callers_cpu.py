@@ -126,3 +126,36 @@ def test_info_nce_known_answer():
     s = torch.cat([cos(q, p) * 20, torch.diagonal(cos(q, n)).unsqueeze(1) * 20], 1)
     want = torch.nn.functional.cross_entropy(s, torch.arange(5))
     assert torch.allclose(callers.info_nce_loss(q, p, n), want, atol=1e-6)
+
+
+def test_infctx_chunks_with_carried_state_equal_one_long_call(gold):
+    """src/model.py:1134-1192 trains long sequences in chunks, carrying (shift_state, wkv_state) per layer
+    (BlockStateList, src/infctx_module.py).  In fp32 the chunked result must equal the single call."""
+    from oracle.wkv6_torch_naive import wkv6_naive
+    from rwkv_lm_ext_amd.infctx import BlockStateList, BlockState, cmix_forward_infctx, tmix_forward_infctx
+    wkv = lambda B, T, C, H, r, k, v, w, u: wkv6_naive(r, k, v, w, u)
+    wkv_s = lambda B, T, C, H, r, k, v, w, u, s: wkv6_naive(r, k, v, w, u, s0=s.float(), return_state=True)
+    tm = callers.Tmix_x060(cw.N_EMBD, cw.DIM_ATT, wkv=wkv)
+    tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
+    cm = callers.CMix_x060(cw.N_EMBD, cw.DIM_FFN)
+    cm.load_state_dict(cw.cmix_weights(torch.Generator().manual_seed(12)), strict=True)
+    x = gold["x"]                                                        # [2, 24, 128]
+    B, T, C = x.shape
+    states = BlockStateList.create(1, B, C, tm.n_head, x.device, x.dtype)
+    assert states.wkv_states.shape == (1, B, 2, 64, 64) and states.wkv_states.dtype == torch.bfloat16
+    assert states.shift_states.shape == (1, 2, B, C)
+    states.wkv_states = states.wkv_states.float()                        # fp32 carry so that the comparison is exact
+    with torch.no_grad():
+        want_t, want_c = tm(x), cm(x)
+        got_t, got_c = [], []
+        for c in range(3):
+            xc = x[:, 8 * c:8 * c + 8]
+            st = states[0]
+            yt, ts = tmix_forward_infctx(tm, xc, st.time_mix_state, wkv_state=wkv_s)
+            yc, cs = cmix_forward_infctx(cm, xc, st.channel_mix_state)
+            states[0] = BlockState(ts, cs)
+            got_t.append(yt)
+            got_c.append(yc)
+    assert max_norm_err(torch.cat(got_t, 1), want_t) <= TOL
+    assert max_norm_err(torch.cat(got_c, 1), want_c) <= TOL
+    assert torch.equal(states.shift_states[0, 0], x[:, -1]) and torch.equal(states.shift_states[0, 1], x[:, -1])

@@ -93,3 +93,23 @@ def test_bi_encoder_training_step_gradients():
             assert e <= 0.12, (n, e)
             checked += 1
     assert checked >= 8
+
+
+def test_infctx_time_mix_on_gpu(gold):
+    """Chunks of 8 with the bf16 wkv state carried through BlockStateList (RUN_CUDA_RWKV6_INFCTX underneath) against
+    the reference module's single-call output."""
+    from rwkv_lm_ext_amd.infctx import BlockStateList, BlockState, ChannelMixState, tmix_forward_infctx
+    tm = callers.Tmix_x060(cw.N_EMBD, cw.DIM_ATT)
+    tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
+    tm = tm.cuda().to(bf)
+    x = gold["x"].cuda().to(bf)
+    B, T, C = x.shape
+    states = BlockStateList.create(1, B, C, tm.n_head, x.device, bf)
+    outs = []
+    with torch.no_grad():
+        for c in range(3):
+            y, ts = tmix_forward_infctx(tm, x[:, 8 * c:8 * c + 8].contiguous(), states[0].time_mix_state)
+            states[0] = BlockState(ts, ChannelMixState(states[0].channel_mix_state.shift_state))
+            outs.append(y)
+    assert max_norm_err(f32(torch.cat(outs, 1)), gold["out"]) <= TOL
+    assert states.wkv_states.dtype == bf and states.wkv_states.abs().sum() > 0

@@ -106,7 +106,7 @@ def test_torch_port_matches_reference():
 def _header_symbols():
     text = open(os.path.join(ROOT, "include", "wkv6_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(wkv6\w*)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(r?wkv6\w*)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

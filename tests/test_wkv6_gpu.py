@@ -394,3 +394,31 @@ def test_forward_checkpoints_feed_backward(ops, oracle):
     for a_, b_ in zip(g0[:5], g1[:5]):
         assert torch.equal(a_, b_)
     check(g1[3], oracle.backward(r, k, v, w, u, gy)["gw"], bf, "ckpt path gw")
+
+
+@pytest.mark.parametrize("io", IOS, ids=["f32", "bf16"])
+def test_rwkv6_stateful_inference_kernel(ops, oracle, io):
+    """cuda/rwkv6.cu: fp32 state in/out, decay already exponentiated; two consecutive calls continue the sequence."""
+    from rwkv_lm_ext_amd.wkv import RUN_RWKV_6
+    B, T, H = 1, 50, 2
+    C = H * 64
+    r, k, v, w, u, _ = rand_inputs(55, B, T, H)
+    g = torch.Generator().manual_seed(56)
+    s0 = (torch.randn(H, 64, 64, generator=g) * 0.5).numpy()
+    yo, so = oracle.forward(r, k, v, w, u, s0, return_state=True)
+    d = [dev(t, io) for t in (r, k, v, w, u)]
+    state = dev(s0, torch.float32)
+    y1, st = RUN_RWKV_6(B, 30, C, H, state, *(t[:, :30].contiguous() for t in d[:4]), d[4])
+    assert st is state
+    y2, _ = RUN_RWKV_6(B, 20, C, H, state, *(t[:, 30:].contiguous() for t in d[:4]), d[4])
+    check(torch.cat([y1, y2], 1), yo, io, "rwkv6 y")
+    assert max_norm_err(host(state), so[0]) <= F32_TOL                       # fp32 state: exact carry
+    # B > 1 (the reference kernel is wrong there): one state per row
+    B2 = 3
+    r, k, v, w, u, _ = rand_inputs(57, B2, 20, H)
+    sb = (torch.randn(B2, H, 64, 64, generator=g) * 0.5).numpy()
+    yo, so = oracle.forward(r, k, v, w, u, sb, return_state=True)
+    stb = dev(sb, torch.float32)
+    y, _ = RUN_RWKV_6(B2, 20, C, H, stb, *(dev(t, io) for t in (r, k, v, w, u)))
+    check(y, yo, io, "rwkv6 batched y")
+    assert max_norm_err(host(stb), so) <= F32_TOL
