@@ -241,9 +241,12 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                     const s4v sc_hi = __builtin_bit_cast(s4v, make_uint2(scp.x, scp.y));
                     const s4v sc_lo = __builtin_bit_cast(s4v, make_uint2(scp.z, scp.w));
                     // (2) y^T[j][a] = sum_b V[b][j] sc[b][a]
-                    f4v yt = {0.f, 0.f, 0.f, 0.f};
-                    yt = mfma16(vf, sc_hi, yt);
-                    yt = mfma16(vf, sc_lo, yt);
+                    // Two accumulators: a 16x16x16 MFMA that takes the result of a 16x16x32 one as SrcC (or the reverse)
+                    // fewer than 5 wait states later reads stale registers on gfx950, and hipcc 7.2 does not pad that
+                    // case ("mixed-shape accumulation"); chains of one shape are interlocked.
+                    f4v yt = {0.f, 0.f, 0.f, 0.f}, yi = {0.f, 0.f, 0.f, 0.f};
+                    yi = mfma16(vf, sc_hi, yi);
+                    yi = mfma16(vf, sc_lo, yi);
                     // (3) y^T[j][a] += sum_i (E8 S)[i][j] Rhat[a][i]; k-slot (s, g, e) <-> channel 32s + 8g + e
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                         const int pc = valid ? p : 0;                    // padding lanes still form a legal address
                         const int t = a.reverse ? ntok - 1 - pc : pc;
                         const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
-                        float o[4] = {yt[0], yt[1], yt[2], yt[3]};
+                        float o[4] = {yt[0] + yi[0], yt[1] + yi[1], yt[2] + yi[2], yt[3] + yi[3]};
                         if constexpr (ACC) {
                             float old[4];
                             if (a.y_f32) io4<float>::load(a.y_f32 + idx, old);

@@ -27,8 +27,11 @@
 //            and gv over i.  A row wave and a column wave share each SIMD, so their VALU/MFMA streams interleave.
 #include "wkv6_chunk.h"
 
+#include <cstdlib>
+
 namespace wkv6 {
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);
+hipError_t launch_chunk_bwd16(const ScanArgs& a, hipStream_t st);
 
 namespace {
 
@@ -311,9 +314,11 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     accr = mfma32(hi, gyr[s], accr);
                     accr = mfma32(lo, gyr[s], accr);
                 }
-                accr = mfma16(khf, dba_hi, accr);                // sum_b Khat[b][i] dA[a][b]
-                accr = mfma16(khf, dba_lo, accr);
-                accr = mfma16(klf, dba_hi, accr);
+                f4v accr16 = {0.f, 0.f, 0.f, 0.f};               // separate accumulator per MFMA shape (see wkv6_chunk.hip)
+                accr16 = mfma16(khf, dba_hi, accr16);            // sum_b Khat[b][i] dA[a][b]
+                accr16 = mfma16(khf, dba_lo, accr16);
+                accr16 = mfma16(klf, dba_hi, accr16);
+                accr += accr16;
                 f4v ak = {0.f, 0.f, 0.f, 0.f};
                 ak = mfma16(rhf_w, dab_hi, ak);                  // sum_a Rhat[a][i] dA[a][b]
                 ak = mfma16(rhf_w, dab_lo, ak);
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                         Oi[jt] = o;
                     }
                 }
-                f4v acck = ackp[blk];
+                f4v acck = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const b8v vr = ld_b8(bb + B_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     acck = mfma32(hi, vr, acck);
                     acck = mfma32(lo, vr, acck);
                 }
+                acck += ackp[blk];
                 {
                     const int ch = 16 * wv + 4 * g;
                     const float4 fk4 = *reinterpret_cast<const float4*>(bb + BOFF_FK + x * FRS + ch * 4);
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 #pragma unroll
             for (int blk = NBLK - 1; blk >= 0; --blk) {
                 const char* const bb = smem + blk * BBLK_BYTES;
-                f4v acc = accp[blk];
+                f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int off = x * RSB + (32 * s + 8 * g) * 2;
@@ -525,6 +531,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     acc = mfma32(gh, kl, acc);
                     acc = mfma32(gl, kh, acc);
                 }
+                acc += accp[blk];
                 {
                     const int p = grp * GRP + blk * BLK + x;
                     if (p < ntok) {
@@ -598,6 +605,8 @@ hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
         sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
         if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
     }
+    static const bool use8 = std::getenv("WKV6_BWD8") != nullptr;     // A/B switch: the 8-wave kernel
+    if (!use8) return launch_chunk_bwd16(a, st);
     return a.wkind ? launch_bwd_variant<true>(a, st) : launch_bwd_variant<false>(a, st);
 }
 
