@@ -12,6 +12,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int BLK = 16;                       // tokens per block
 constexpr int NBLK = 4;                       // blocks per group (= waves)
 constexpr int GRP = BLK * NBLK;               // 64 tokens per group
+constexpr int CKPT_TOK = 32;                  // the forward leaves an fp32 state checkpoint every CKPT_TOK tokens
 constexpr int RSB = 160;                      // bytes per staged token row (64 bf16 + 16 pad): ds_read_b128 row reads and
                                               // ds_read_b64_tr_b16 are both conflict-free at this stride (144 B is 2-way on both)
 constexpr int ARR = BLK * RSB;                // one operand array
@@ -55,15 +56,24 @@ __device__ __forceinline__ b8v ld_b8_2x4(const char* p0, const char* p1)
     const uint4 v = make_uint4(a.x, a.y, b.x, b.y);
     return __builtin_bit_cast(b8v, v);
 }
-// split 4 floats into packed bf16 hi and lo parts
+// split 4 floats into packed bf16 hi and lo parts.  lo = x - float(hi) is formed by v_dot2(c)_f32_bf16 straight from
+// the packed hi pair (hi.(-1,0) + x, exact: every partial result is representable), ~2 cycles per element where the
+// unpack (shift 4, and 2.3) + subtract (2) path costs ~6 (issue rates: DESIGN.md section 4).
 __device__ __forceinline__ void split4(const float (&x)[4], uint2& hi, uint2& lo)
 {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    // (-1, 0) and (0, -1) as packed bf16.  Kept opaque: hipcc 7.2 folds such a pair into the inline constant -1.0, which
+    // the hardware does not expand to (bf16 -1, 0) for this instruction (results were off by whole terms).
+    unsigned c10 = 0x0000bf80u, c01 = 0xbf800000u;
+    asm("" : "+v"(c10));
+    asm("" : "+v"(c01));
+    const bf2 m10 = __builtin_bit_cast(bf2, c10), m01 = __builtin_bit_cast(bf2, c01);
     hi.x = pack_bf2(x[0], x[1]);
     hi.y = pack_bf2(x[2], x[3]);
-    lo.x = pack_bf2(x[0] - bf_lo(hi.x), x[1] - bf_hi(hi.x));
-    lo.y = pack_bf2(x[2] - bf_lo(hi.y), x[3] - bf_hi(hi.y));
+    const bf2 h0 = __builtin_bit_cast(bf2, hi.x), h1 = __builtin_bit_cast(bf2, hi.y);
+    lo.x = pack_bf2(__builtin_amdgcn_fdot2_f32_bf16(h0, m10, x[0], false), __builtin_amdgcn_fdot2_f32_bf16(h0, m01, x[1], false));
+    lo.y = pack_bf2(__builtin_amdgcn_fdot2_f32_bf16(h1, m10, x[2], false), __builtin_amdgcn_fdot2_f32_bf16(h1, m01, x[3], false));
 }
-
 
 }  // namespace chunk
 }  // namespace wkv6

@@ -41,7 +41,7 @@ using namespace chunk;
 constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 
 // STATE_ONLY: no outputs, only the state recurrence (first half of the self-contained backward).
-// With a.ckpt the state at the entry of every 64-token group is dumped (fp32, register order:
+// With a.ckpt the state at the entry of every 32-token stage is dumped (fp32, register order:
 // [wave][tile][lane][4]) for the backward kernel.
 // ACC: add into y (from a.y_f32 when given) instead of overwriting -- the reverse half of wkv6_bi.
 template <bool W_RAW, bool STATE_ONLY, bool ACC>
@@ -221,18 +221,18 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             // every ds_read_b64_tr_b16 address of this iteration depends on this statement, which cannot move above the
             // barrier: the transposed reads are guaranteed to be issued after the producers' writes are visible
             asm volatile("" : "+v"(troff), "+v"(trow));
-            if (a.ckpt) {
-                float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + GRP - 1) / GRP) + grp) * (HEAD * HEAD);
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    *reinterpret_cast<float4*>(ck + ((wv * 4 + it) * 64 + lane) * 4) =
-                        make_float4(St[it][0], St[it][1], St[it][2], St[it][3]);
-            }
             // Rolled on purpose (runtime trip count): a fully unrolled 4-block body was measured no faster and was
             // miscompiled by hipcc 7.2 (wrong y in the first block of a group).
             const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
+                if (a.ckpt && !(blk & 1)) {   // state at the entry of every 32-token stage, for the backward kernel
+                    float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + CKPT_TOK - 1) / CKPT_TOK) + grp * (GRP / CKPT_TOK) + (blk >> 1)) * (HEAD * HEAD);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        *reinterpret_cast<float4*>(ck + ((wv * 4 + it) * 64 + lane) * 4) =
+                            make_float4(St[it][0], St[it][1], St[it][2], St[it][3]);
+                }
                 // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
                 const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);
                 if constexpr (!STATE_ONLY) {
@@ -350,7 +350,7 @@ hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st)
 
 size_t chunk_ckpt_floats(int B, int T, int H)
 {
-    return (size_t)B * H * ((T + GRP - 1) / GRP) * HEAD * HEAD;
+    return (size_t)B * H * ((T + CKPT_TOK - 1) / CKPT_TOK) * HEAD * HEAD;
 }
 
 }  // namespace wkv6

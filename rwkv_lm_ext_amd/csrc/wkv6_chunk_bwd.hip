@@ -89,7 +89,6 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const long base = (long)b * a.T * a.C + (long)h * HEAD;
-    const int ngmax = (a.T + GRP - 1) / GRP;
 
     // ---- phase-P role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block wv
     const int c8i = lane & 7, tq = lane >> 3;
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             {   // group-entry forward state (dumped in the forward kernel's register order)
-                const float* const ck = a.ckpt + ((long)blockIdx.x * ngmax + grp) * (HEAD * HEAD);
+                const float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + CKPT_TOK - 1) / CKPT_TOK) + grp * (GRP / CKPT_TOK)) * (HEAD * HEAD);
                 // element S[i = 16wv + x][j]: forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), reg i&3
                 const int i_ = 16 * wv + x;
                 const int fit = 2 * (i_ >> 5) + ((i_ >> 2) & 1), fg = (i_ >> 3) & 3, fq = i_ & 3;

@@ -14,23 +14,32 @@
 //   gu       += vg_a r_a (.) k_a
 // i.e. the adjoint of cuda/wkv6_cuda.cu:44-57 (reference backward: cuda/wkv6_cuda.cu:63-227), re-associated.
 //
-// The kernel is latency bound, not pipe bound (at 8 waves: VALU ~22 %, MFMA ~28 %, LDS ~31 % of peak), so the
-// design goal is many independent waves per SIMD with balanced work.  One 1024-thread workgroup (16 wave64, four
-// per SIMD, <= 128 VGPRs) per (batch, head) walks the 64-token groups backwards:
-//   phase P (all 16 waves): wave (q, w) turns channels [16q, 16q+16) of block w into MFMA operands in LDS
-//            (lane = token x 4 channels; the cumulative decays are DPP row prefix sums);
-//   phase C: four roles of four waves each (one of each role per SIMD)
-//     R  waves own key rows [16w, 16w+16) of the FORWARD state (lane = key row).  They need no G, so they walk
-//        the four blocks of the group forwards from the group-entry checkpoint the forward kernel left:
-//        gr, gu, and a_t = r (.) dq, which they leave in LDS for the K wave of the same rows;
-//     K  waves own the same key rows of G (lane = key row): dk, gk, then -- once the R partner has flagged its
-//        a_t -- gw with its running suffix sum;
-//     J0/J1 waves own value columns [16w, 16w+16) of G (lane = value column), J0 the key rows [0,32), J1 [32,64):
-//        each produces half of the contraction over i for gv; J1 leaves its partial tile in LDS, J0 adds it after
-//        the group barrier and stores gv.  The score tile of a block is built by one of the two (by parity).
-//     G is therefore held in both orientations (gk contracts it over j, gv over i); the R -> K handoff is a
-//     release/acquire flag in LDS (producer never waits), the J1 -> J0 handoff rides on the group barrier.
+// Machine facts that shape the kernel (measured on MI355X, scratch microbenchmarks in DESIGN.md section 4): fp32
+// VALU issues at ~2.3 cycles per wave64 instruction, integer / DPP / packed-f32 / cvt / transcendental ops at ~4,
+// either MFMA shape at 16; the block algebra costs ~3.7 wave-instructions per token-channel, so the kernel is
+// bound by instruction issue and dependency latency, not by HBM, LDS or the matrix pipe.  Hence: many waves per
+// SIMD, balanced roles, and operand preparation overlapped with the chains instead of serialised before them.
+//
+// One 1024-thread workgroup (16 wave64, four per SIMD, <= 128 VGPRs) per (batch, head) walks 32-token stages
+// (two 16-token blocks) backwards through a double-buffered LDS image; one workgroup barrier per stage.
+// Four roles of four waves (one of each role per SIMD):
+//   R  waves own key rows [16w, 16w+16) of the FORWARD state (lane = key row).  They need no G: they start each
+//      stage from the checkpoint the forward kernel left (fp32, every 32 tokens) and walk its two blocks forwards:
+//      gr, gu, and a_t = r (.) dq, which they leave in LDS (in place of fR) for the K wave of the same rows;
+//   K  waves own the same key rows of G (lane = key row): dk, gk, then -- once the R partner has flagged its
+//      a_t -- gw with its running suffix sum;
+//   J0/J1 waves own value columns [16w, 16w+16) of G (lane = value column), J0 the key rows [0,32), J1 [32,64):
+//      each produces half of the contraction over i for gv; J1 leaves its partial tile in LDS, J0 adds it after
+//      the stage barrier and stores gv.  The score tile of a block is built by one of the two (by parity).
+//      The eight J waves also turn the NEXT stage (wave = block x channel quarter, lane = token x 4 channels;
+//      cumulative decays are DPP row prefix sums) into MFMA operands in the other LDS buffer and issue the global
+//      loads of the stage after that, so preparation overlaps the chains of the other roles.
+//   G is held in both orientations (gk contracts it over j, gv over i); the R -> K handoff is a release/acquire
+//   flag in LDS (the producer never waits), the J1 -> J0 handoff rides on the stage barrier.
 #include "wkv6_chunk.h"
+#ifdef DBG_TIME
+#include <cstdio>
+#endif
 
 namespace wkv6 {
 namespace {
@@ -47,13 +56,27 @@ constexpr int BOFF_E16 = BOFF_E8 + 256;
 constexpr int BOFF_E16M8 = BOFF_E16 + 256;
 constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float [4][16]  per-quarter sum_i r u k
 constexpr int BBLK_BYTES = BOFF_COEF + 256;
-constexpr int OFF_PART = NBLK * BBLK_BYTES;                            // float4 [NBLK][4][64]  J1's partial gv tiles
-constexpr int OFF_FLAG = OFF_PART + NBLK * 4 * 64 * 16;                // int [4]  last group whose a_t the R wave has published
+constexpr int STG = CKPT_TOK;                                          // tokens per stage (= forward checkpoint spacing)
+constexpr int SBLK = STG / BLK;                                        // blocks per stage
+constexpr int BUF_BYTES = SBLK * BBLK_BYTES;                           // one stage image; two of them
+constexpr int OFF_PART = 2 * BUF_BYTES;                                // float4 [2][SBLK][4][64]  J1's partial gv tiles, by stage parity
+constexpr int OFF_FLAG = OFF_PART + 2 * SBLK * 4 * 64 * 16;            // int [4]  last stage whose a_t the R wave has published
 constexpr int LDS_BYTES = OFF_FLAG + 64;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-constexpr int DPP_SHL1 = 0x101, DPP_SHL2 = 0x102, DPP_SHL4 = 0x104, DPP_SHL8 = 0x108;   // row_shl:n, zero fill
-constexpr int DPP_SHR1 = 0x111, DPP_SHR2 = 0x112, DPP_SHR4 = 0x114, DPP_SHR8 = 0x118;   // row_shr:n, zero fill
+// x += x shifted by n lanes within the 16-lane row, as ONE v_add_f32_dpp (the compiler emits v_mov_dpp + v_add for the
+// builtin).  Lanes whose source falls outside the row are disabled by the DPP rules (bound_ctrl off) and keep x.
+#define WKV6_DPP_ACC(x, ctrl) asm("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
+__device__ __forceinline__ float row_prefix16(float x)
+{   // inclusive prefix sum over the 16 lanes of a DPP row
+    WKV6_DPP_ACC(x, "row_shr:1"); WKV6_DPP_ACC(x, "row_shr:2"); WKV6_DPP_ACC(x, "row_shr:4"); WKV6_DPP_ACC(x, "row_shr:8");
+    return x;
+}
+__device__ __forceinline__ float row_suffix16(float x)
+{   // inclusive suffix sum over the 16 lanes of a DPP row
+    WKV6_DPP_ACC(x, "row_shl:1"); WKV6_DPP_ACC(x, "row_shl:2"); WKV6_DPP_ACC(x, "row_shl:4"); WKV6_DPP_ACC(x, "row_shl:8");
+    return x;
+}
 
 __device__ __forceinline__ float pick4(const f4v& v, int s)
 {
@@ -93,21 +116,23 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const long base = (long)b * a.T * a.C + (long)h * HEAD;
-    const int ngmax = (a.T + GRP - 1) / GRP;
-    const int ngrp = (ntok + GRP - 1) / GRP;
+    const int nstmax = (a.T + STG - 1) / STG;
+    const int nst = (ntok + STG - 1) / STG;
     int* const flags = reinterpret_cast<int*>(smem + OFF_FLAG);
-    if (tid < 4) flags[tid] = ngrp;                                      // no group has this index
+    if (tid < 4) flags[tid] = nst;                                       // no stage has this index
 
-    // ---- phase-P role: token ptok of block wv, channels ch0..ch0+3
+    // ---- preparation role of the J waves: token ptok of block pb, channels ch0..ch0+3
+    const int jw = wid & 7;
+    const int pb = jw & 1, cq = jw >> 1;
     const int ptok = lane & 15, pc4 = lane >> 4;
-    const int ch0 = 16 * role + 4 * pc4;
+    const int ch0 = 16 * cq + 4 * pc4;
     float uu[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + ch0, uu);
 
     uint2 pr, pk, pv, pg, pw;
     float4 pe;
-    auto load_group = [&](int grp) {
-        const int p = grp * GRP + wv * BLK + ptok;
+    auto load_stage = [&](int st) {
+        const int p = st * STG + pb * BLK + ptok;
         pr = pk = pv = pg = pw = make_uint2(0u, 0u);
         pe = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < ntok) {
@@ -122,9 +147,9 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
         }
     };
 
-    auto prep_group = [&](int grp) {
-        char* const bb = smem + wv * BBLK_BYTES;
-        const bool valid = grp * GRP + wv * BLK + ptok < ntok;
+    auto prep_stage = [&](int st) {
+        char* const bb = smem + (st & 1) * BUF_BYTES + pb * BBLK_BYTES;
+        const bool valid = st * STG + pb * BLK + ptok < ntok;
         const float r[4] = {bf_lo(pr.x), bf_hi(pr.x), bf_lo(pr.y), bf_hi(pr.y)};
         const float k[4] = {bf_lo(pk.x), bf_hi(pk.x), bf_lo(pk.y), bf_hi(pk.y)};
         float lw[4];
@@ -139,21 +164,20 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             lws[c] = valid ? fmaxf(lw[c], LW_MIN) : 0.f;                  // the decay the block algebra uses
-            // gw multiplier: the true lw, times d_true / d_clamped where the clamp is active (the algebra yields the
-            // exact gradient of the clamped model, d_clamped * X; the true one is d_true * X)
-            lwe[c] = valid ? lw[c] * __expf(fminf(lw[c] - LW_MIN, 0.f)) : 0.f;
+            lwe[c] = valid ? lw[c] : 0.f;
             part = fmaf(r[c] * uu[c], k[c], part);
-            float s = lws[c];                                             // inclusive prefix over the 16 tokens of the row
-            s += dpp_mov<DPP_SHR1>(s);
-            s += dpp_mov<DPP_SHR2>(s);
-            s += dpp_mov<DPP_SHR4>(s);
-            s += dpp_mov<DPP_SHR8>(s);
-            inc[c] = s;
+            inc[c] = row_prefix16(lws[c]);                                // inclusive prefix over the 16 tokens of the row
+        }
+        // gw multiplier: the true lw, times d_true / d_clamped where the clamp is active (the algebra yields the exact
+        // gradient of the clamped model, d_clamped * X; the true one is d_true * X).  Rare: skipped wave-uniformly.
+        if (__builtin_amdgcn_ballot_w64(lwe[0] < LW_MIN || lwe[1] < LW_MIN || lwe[2] < LW_MIN || lwe[3] < LW_MIN)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lwe[c] *= __expf(fminf(lwe[c] - LW_MIN, 0.f));
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);                                     // the 4 lanes that share this token
         char* const row = bb + ptok * RSB + ch0 * 2;
-        if (pc4 == 0) *reinterpret_cast<float*>(bb + BOFF_COEF + (role * 16 + ptok) * 4) = part;
+        if (pc4 == 0) *reinterpret_cast<float*>(bb + BOFF_COEF + (cq * 16 + ptok) * 4) = part;
         *reinterpret_cast<uint2*>(row + B_V * ARR) = pv;
         *reinterpret_cast<uint2*>(row + B_GY * ARR) = pg;
         *reinterpret_cast<uint2*>(row + B_R * ARR) = pr;
@@ -185,11 +209,24 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
         *reinterpret_cast<float4*>(bb + BOFF_FK + ptok * FRS + ch0 * 4) = make_float4(fk[0], fk[1], fk[2], fk[3]);
     };
 
-    // ---- phase-C lane roles
+    // ---- lane roles in the chains
     const int x = lane & 15, g = lane >> 4;
     int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);          // transposed read, natural columns (own tile)
     int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);          // transposed read, tile-labelled columns: + tile_tr(t)
-    if (ngrp > 0) load_group(ngrp - 1);
+#ifdef DBG_TIME
+    long long tacc[4] = {0, 0, 0, 0}, tt0, tt1;
+#define TSTART tt0 = clock64();
+#define TLAP(i) tt1 = clock64(); tacc[i] += tt1 - tt0; tt0 = tt1;
+#else
+#define TSTART
+#define TLAP(i)
+#endif
+    if (role >= 2 && nst > 0) {   // first stage image
+        load_stage(nst - 1);
+        prep_stage(nst - 1);
+        if (nst > 1) load_stage(nst - 2);
+    }
+    __syncthreads();
 
     if (role == 0) {
         // =============== R: key rows [16wv, 16wv+16) of the forward state: gr, gu, a_t ====================
@@ -197,31 +234,36 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
         float ue[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
         float gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int grp = ngrp - 1; grp >= 0; --grp) {
-            f4v ST[4];
-            {   // group-entry forward state (dumped in the forward kernel's register order)
-                const float* const ck = a.ckpt + ((long)blockIdx.x * ngmax + grp) * (HEAD * HEAD);
-                // element S[i = 16wv + x][j]: forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), reg i&3
-                const int i_ = 16 * wv + x;
-                const int fit = 2 * (i_ >> 5) + ((i_ >> 2) & 1), fg = (i_ >> 3) & 3, fq = i_ & 3;
+        f4v SN[4];                                                // next stage's entry state, loaded one stage ahead
+        auto load_ckpt = [&](int st) {
+            // forward state at the entry of stage st (dumped in the forward kernel's register order):
+            // element S[i = 16wv + x][j]: forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), reg i&3
+            const float* const ck = a.ckpt + ((long)blockIdx.x * nstmax + st) * (HEAD * HEAD);
+            const int i_ = 16 * wv + x;
+            const int fit = 2 * (i_ >> 5) + ((i_ >> 2) & 1), fg = (i_ >> 3) & 3, fq = i_ & 3;
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    float t4[4];
+            for (int jt = 0; jt < 4; ++jt) {
+                float t4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int j_ = tile_ch(jt) + 8 * g + q;
-                        t4[q] = ck[(((j_ >> 4) * 4 + fit) * 64 + 16 * fg + (j_ & 15)) * 4 + fq];
-                    }
-                    ST[jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
+                for (int q = 0; q < 4; ++q) {
+                    const int j_ = tile_ch(jt) + 8 * g + q;
+                    t4[q] = ck[(((j_ >> 4) * 4 + fit) * 64 + 16 * fg + (j_ & 15)) * 4 + fq];
                 }
+                SN[jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
             }
-            prep_group(grp);
-            __syncthreads();
-            asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this iteration below the barrier
-            if (grp > 0) load_group(grp - 1);
-#pragma unroll 1
-            for (int blk = 0; blk < NBLK; ++blk) {
-                char* const bb = smem + blk * BBLK_BYTES;
+        };
+        if (nst > 0) load_ckpt(nst - 1);
+        for (int st = nst - 1; st >= 0; --st) {
+            TSTART
+            asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this stage below the barrier
+            f4v ST[4];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) ST[jt] = SN[jt];
+            if (st > 0) load_ckpt(st - 1);
+            char* const buf = smem + (st & 1) * BUF_BYTES;
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                char* const bb = buf + blk * BBLK_BYTES;
                 f4v dA_ba = {0.f, 0.f, 0.f, 0.f};
                 b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: also the B operand of accr
 #pragma unroll
@@ -241,43 +283,41 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                 const s4v dba_hi = __builtin_bit_cast(s4v, th), dba_lo = __builtin_bit_cast(s4v, tl);
                 const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);        // Khat[4g+e][16wv + x]
                 const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
-                const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
-                // gr accumulator [i_local = 4g+q][token x]
-                f4v accr = {0.f, 0.f, 0.f, 0.f};
+                // gr accumulators [i_local = 4g+q][token x], one per MFMA shape (see wkv6_chunk.hip); the E8 row scale of
+                // the state term is applied to the 4 results instead of the 16 operands
+                f4v accs_ = {0.f, 0.f, 0.f, 0.f}, acci = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    float t0[4], t1[4];
+                    const float t0[4] = {ST[2 * s][0], ST[2 * s][1], ST[2 * s][2], ST[2 * s][3]};
+                    const float t1[4] = {ST[2 * s + 1][0], ST[2 * s + 1][1], ST[2 * s + 1][2], ST[2 * s + 1][3]};
                     b8v hi, lo;                                  // k-slot (s, g, e) <-> value channel 32s + 8g + e
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { t0[q] = ST[2 * s][q] * e8x; t1[q] = ST[2 * s + 1][q] * e8x; }
                     split8(t0, t1, hi, lo);
-                    accr = mfma32(hi, gyr[s], accr);
-                    accr = mfma32(lo, gyr[s], accr);
+                    accs_ = mfma32(hi, gyr[s], accs_);
+                    accs_ = mfma32(lo, gyr[s], accs_);
                 }
-                f4v accr16 = {0.f, 0.f, 0.f, 0.f};               // separate accumulator per MFMA shape (see wkv6_chunk.hip)
-                accr16 = mfma16(khf, dba_hi, accr16);            // sum_b Khat[b][i] dA[a][b]
-                accr16 = mfma16(khf, dba_lo, accr16);
-                accr16 = mfma16(klf, dba_hi, accr16);
-                accr += accr16;
+                acci = mfma16(khf, dba_hi, acci);                // sum_b Khat[b][i] dA[a][b]
+                acci = mfma16(khf, dba_lo, acci);
+                acci = mfma16(klf, dba_hi, acci);
                 {   // gr, a_t, gu: lane = token x, channels ch .. ch+3
                     const int ch = 16 * wv + 4 * g;
                     float4* const frp = reinterpret_cast<float4*>(bb + BOFF_FR + x * FRS + ch * 4);
                     const float4 fr4 = *frp;
+                    const float4 e84 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + ch * 4);
                     const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
                     const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
-                    const float frv[4] = {fr4.x, fr4.y, fr4.z, fr4.w};
+                    const float frv[4] = {fr4.x, fr4.y, fr4.z, fr4.w}, e8v[4] = {e84.x, e84.y, e84.z, e84.w};
                     const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
                     const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
                     float o_gr[4], at[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float dq = frv[q] * accr[q];
+                        const float dq = frv[q] * fmaf(e8v[q], accs_[q], acci[q]);
                         o_gr[q] = fmaf(vg * ue[q], kv[q], dq);
                         gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
                         at[q] = rv[q] * dq;
                     }
                     *frp = make_float4(at[0], at[1], at[2], at[3]);      // same lane, same address: fR is consumed
-                    const int p = grp * GRP + blk * BLK + x;
+                    const int p = st * STG + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
                         const long idx = base + (long)t * a.C + ch;
@@ -290,7 +330,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                         io4<bf16_t>::store(ogr + idx, o_gr);
                     }
                 }
-                if (blk < NBLK - 1) {   // entry state of the next block:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
+                if (blk < SBLK - 1) {   // entry state of the next block:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
                     const float e16 = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
                     const float e16m8 = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
 #pragma unroll
@@ -304,10 +344,12 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                     }
                 }
             }
-            // publish a_t of this group to the K wave of the same rows
+            // publish a_t of this stage to the K wave of the same rows
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(flags + wv, grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) __hip_atomic_store(flags + wv, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            TLAP(2)
             __syncthreads();
+            TLAP(3)
         }
         if (a.gu) {
             float s4[4];
@@ -324,14 +366,13 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
 #pragma unroll
         for (int t = 0; t < 4; ++t) GI[t] = f4v{0.f, 0.f, 0.f, 0.f};
         float Rc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int grp = ngrp - 1; grp >= 0; --grp) {
-            prep_group(grp);
-            __syncthreads();
+        for (int st = nst - 1; st >= 0; --st) {
+            TSTART
             asm volatile("" : "+v"(troff), "+v"(trow));
-            if (grp > 0) load_group(grp - 1);
-#pragma unroll 1
-            for (int blk = NBLK - 1; blk >= 0; --blk) {
-                char* const bb = smem + blk * BBLK_BYTES;
+            char* const buf = smem + (st & 1) * BUF_BYTES;
+#pragma unroll
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                char* const bb = buf + blk * BBLK_BYTES;
                 f4v dA_ab = {0.f, 0.f, 0.f, 0.f};
                 b8v vr[2];
 #pragma unroll
@@ -352,22 +393,19 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                 const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
                 const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
                 const float e16x = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
-                const float e16m8x = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
-                f4v acck = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};   // one accumulator per MFMA shape
+                f4v accg = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};   // one accumulator per MFMA shape
                 ak = mfma16(rhf_w, dab_hi, ak);                  // sum_a Rhat[a][i] dA[a][b]
                 ak = mfma16(rhf_w, dab_lo, ak);
                 ak = mfma16(rlf_w, dab_hi, ak);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float t0[4], t1[4];
+                for (int s = 0; s < 2; ++s) {                    // (G v_b)[i]; its E16m8 row scale is applied to the result
+                    const float t0[4] = {GI[2 * s][0], GI[2 * s][1], GI[2 * s][2], GI[2 * s][3]};
+                    const float t1[4] = {GI[2 * s + 1][0], GI[2 * s + 1][1], GI[2 * s + 1][2], GI[2 * s + 1][3]};
                     b8v hi, lo;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
                     split8(t0, t1, hi, lo);
-                    acck = mfma32(hi, vr[s], acck);
-                    acck = mfma32(lo, vr[s], acck);
+                    accg = mfma32(hi, vr[s], accg);
+                    accg = mfma32(lo, vr[s], accg);
                 }
-                acck += ak;
                 // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {                 // [row j_local][col i_local = x]
@@ -378,24 +416,25 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * o[q]);
                 }
-                {   // gk now; b_t = k (.) dk kept for gw
+                {   // gk now; b_t = k (.) dk goes to LDS (in place of fK) for the gw pass
                     const int ch = 16 * wv + 4 * g;
                     float4* const fkp = reinterpret_cast<float4*>(bb + BOFF_FK + x * FRS + ch * 4);
                     const float4 fk4 = *fkp;
+                    const float4 m84 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + ch * 4);
                     const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
                     const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
-                    const float fkv[4] = {fk4.x, fk4.y, fk4.z, fk4.w};
+                    const float fkv[4] = {fk4.x, fk4.y, fk4.z, fk4.w}, m8v[4] = {m84.x, m84.y, m84.z, m84.w};
                     const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
                     const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
                     float o_gk[4], bt[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float dk = fkv[q] * acck[q];
+                        const float dk = fkv[q] * fmaf(m8v[q], accg[q], ak[q]);
                         o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
                         bt[q] = kv[q] * dk;
                     }
                     *fkp = make_float4(bt[0], bt[1], bt[2], bt[3]);      // same lane, same address: fK is consumed
-                    const int p = grp * GRP + blk * BLK + x;
+                    const int p = st * STG + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
                         const long idx = base + (long)t * a.C + ch;
@@ -410,32 +449,28 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                 }
             }
             // ---- gw: needs a_t of the R wave that owns the same key rows
-            while (__hip_atomic_load(flags + wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp)
+            while (__hip_atomic_load(flags + wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != st)
                 __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll 1
-            for (int blk = NBLK - 1; blk >= 0; --blk) {
-                const char* const bb = smem + blk * BBLK_BYTES;
+#pragma unroll
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                const char* const bb = buf + blk * BBLK_BYTES;
                 const int ch = 16 * wv + 4 * g;
                 const float4 at4 = *reinterpret_cast<const float4*>(bb + BOFF_FR + x * FRS + ch * 4);
                 const float4 bt4 = *reinterpret_cast<const float4*>(bb + BOFF_FK + x * FRS + ch * 4);
-                const float bt[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
                 const float4 lw4 = *reinterpret_cast<const float4*>(bb + BOFF_LW + x * FRS + ch * 4);
-                const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
+                const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, btv[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
+                const float lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
                 float o_gw[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float dl = atv[q] - bt[q];
-                    float sfx = dl;                               // inclusive suffix sum over the later tokens of the row
-                    sfx += dpp_mov<DPP_SHL1>(sfx);
-                    sfx += dpp_mov<DPP_SHL2>(sfx);
-                    sfx += dpp_mov<DPP_SHL4>(sfx);
-                    sfx += dpp_mov<DPP_SHL8>(sfx);
+                    const float dl = atv[q] - btv[q];
+                    const float sfx = row_suffix16(dl);           // inclusive suffix sum over the later tokens of the row
                     const float total = __shfl(sfx, lane & 48);
-                    o_gw[q] = (Rc[q] + (sfx - dl) - bt[q]) * lwv[q];
+                    o_gw[q] = (Rc[q] + sfx - atv[q]) * lwv[q];    // Rc + (sfx - dl) - b_t
                     Rc[q] += total;
                 }
-                const int p = grp * GRP + blk * BLK + x;
+                const int p = st * STG + blk * BLK + x;
                 if (p < ntok) {
                     const int t = a.reverse ? ntok - 1 - p : p;
                     const long idx = base + (long)t * a.C + ch;
@@ -448,7 +483,9 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                     io4<bf16_t>::store(ogw + idx, o_gw);
                 }
             }
+            TLAP(2)
             __syncthreads();
+            TLAP(3)
         }
     } else {
         // =============== J0 / J1: value columns [16wv, 16wv+16) x key rows [32ih, 32ih+32) of G: gv, gs =====
@@ -456,16 +493,20 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
         const int ih = role - 2;
         f4v GJ[2];
         GJ[0] = GJ[1] = f4v{0.f, 0.f, 0.f, 0.f};
-        float4* const part = reinterpret_cast<float4*>(smem + OFF_PART) + wv * 64 + lane;      // + blk * 256
-        for (int grp = ngrp - 1; grp >= 0; --grp) {
-            prep_group(grp);
-            __syncthreads();
+        float4* const part = reinterpret_cast<float4*>(smem + OFF_PART) + wv * 64 + lane;      // + (parity * SBLK + blk) * 256
+        for (int st = nst - 1; st >= 0; --st) {
+            TSTART
+            if (st > 0) {   // operands of the next stage into the other buffer; global loads of the one after
+                prep_stage(st - 1);
+                if (st > 1) load_stage(st - 2);
+            }
+            TLAP(0)
             asm volatile("" : "+v"(troff), "+v"(trow));
-            if (grp > 0) load_group(grp - 1);
-            f4v accs[NBLK];
+            const char* const buf = smem + (st & 1) * BUF_BYTES;
+            f4v accs[SBLK];
 #pragma unroll
-            for (int blk = NBLK - 1; blk >= 0; --blk) {
-                const char* const bb = smem + blk * BBLK_BYTES;
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                const char* const bb = buf + blk * BBLK_BYTES;
                 const s4v gyT_w = tr_read(bb + B_GY * ARR + troff + 32 * wv);      // gy[4g+e][16wv + x]
                 f4v acc = {0.f, 0.f, 0.f, 0.f}, acci = {0.f, 0.f, 0.f, 0.f};   // gv^T[j][b]; one accumulator per MFMA shape
                 if ((blk & 1) == ih) {   // the intra-block part, sum_a gy[a][j] A[a][b]: one of the two J waves per block
@@ -481,8 +522,8 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                     }
                     float cf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int cq = 0; cq < 4; ++cq) {
-                        const float4 c4 = *reinterpret_cast<const float4*>(bb + BOFF_COEF + cq * 64 + 16 * g);
+                    for (int c = 0; c < 4; ++c) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(bb + BOFF_COEF + c * 64 + 16 * g);
                         cf[0] += c4.x; cf[1] += c4.y; cf[2] += c4.z; cf[3] += c4.w;
                     }
                     float scm[4];
@@ -510,32 +551,32 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                     acc = mfma32(gl, kh, acc);
                 }
                 acc += acci;
-                if (ih) part[blk * 256] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                if (ih) part[((st & 1) * SBLK + blk) * 256] = make_float4(acc[0], acc[1], acc[2], acc[3]);
                 accs[blk] = acc;
                 // ---- G[half][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int it = 2 * ih + t;
-                    const s4v rhf = tr_read(bb + B_RH * ARR + trow + tile_tr(0) + 64 * ih + 8 * t);
-                    const s4v rlf = tr_read(bb + B_RL * ARR + trow + tile_tr(0) + 64 * ih + 8 * t);
+                    const s4v rhf = tr_read(bb + B_RH * ARR + trow + tile_tr(2 * ih + t));
+                    const s4v rlf = tr_read(bb + B_RL * ARR + trow + tile_tr(2 * ih + t));
                     f4v o = {0.f, 0.f, 0.f, 0.f};                 // [row i_local][col j_local = x]
                     o = mfma16(rhf, gyT_w, o);
                     o = mfma16(rlf, gyT_w, o);
                     const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (32 * ih + 4 * t + 8 * g) * 4);
                     const float4 d8 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (32 * ih + 4 * t + 8 * g) * 4);
-                    (void)it;
                     GJ[t][0] = fmaf(d16.x, GJ[t][0], d8.x * o[0]);
                     GJ[t][1] = fmaf(d16.y, GJ[t][1], d8.y * o[1]);
                     GJ[t][2] = fmaf(d16.z, GJ[t][2], d8.z * o[2]);
                     GJ[t][3] = fmaf(d16.w, GJ[t][3], d8.w * o[3]);
                 }
             }
+            TLAP(2)
             __syncthreads();
-            if (ih == 0) {   // J1's halves are in LDS now (it rewrites them only after the next group's first barrier)
+            TLAP(3)
+            if (ih == 0) {   // J1's halves are in LDS now (it rewrites this parity only two stages later)
 #pragma unroll
-                for (int blk = 0; blk < NBLK; ++blk) {
-                    const int p = grp * GRP + blk * BLK + x;
-                    const float4 o1 = part[blk * 256];
+                for (int blk = 0; blk < SBLK; ++blk) {
+                    const int p = st * STG + blk * BLK + x;
+                    const float4 o1 = part[((st & 1) * SBLK + blk) * 256];
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
                         const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
@@ -560,6 +601,10 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
             }
         }
     }
+#ifdef DBG_TIME
+    if (a.aux && blockIdx.x == 7 && lane == 0)
+        for (int i = 0; i < 4; ++i) a.aux[wid * 4 + i] = (float)tacc[i];
+#endif
     if (a.zero_tail && !a.accumulate) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += 64) {
@@ -581,6 +626,26 @@ template <bool W_RAW> hipError_t launch_bwd16_variant(const ScanArgs& a, hipStre
         if (e != hipSuccess) return e;
         configured = true;
     }
+#ifdef DBG_TIME
+    {
+        static float* dbg = nullptr;
+        if (!dbg) hipMalloc(&dbg, 64 * 4);
+        ScanArgs a2 = a; a2.aux = dbg;
+        hipLaunchKernelGGL((chunk_bwd16_kernel<W_RAW>), dim3(a.B * a.H), dim3(1024), (size_t)LDS_BYTES, st, a2);
+        hipDeviceSynchronize();
+        float host[64];
+        hipMemcpy(host, dbg, 64 * 4, hipMemcpyDeviceToHost);
+        static int calls = 0;
+        if (++calls == 3) {
+            const int ng = (a.T + STG - 1) / STG;
+            const char* rn[4] = {"R ", "K ", "J0", "J1"};
+            for (int w = 0; w < 16; ++w)
+                printf("%s wave %d: per stage  prep %7.0f  wait %7.0f  work %7.0f  wait %7.0f\n", rn[w >> 2], w & 3,
+                       host[w * 4] / ng, host[w * 4 + 1] / ng, host[w * 4 + 2] / ng, host[w * 4 + 3] / ng);
+        }
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((chunk_bwd16_kernel<W_RAW>), dim3(a.B * a.H), dim3(1024), (size_t)LDS_BYTES, st, a);
     return hipGetLastError();
 }
