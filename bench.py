@@ -32,11 +32,11 @@ FWD_BYTES, BWD_BYTES = 10, 18   # per token-channel
 
 def measured_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_chunk_final_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE
+    (profiles/r01_final_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot read PMCs itself, so this is the
     number measured for the headline workload with the committed kernels; None for any other workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_chunk_final_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_final_pmc.json")) as f:
             return int(json.load(f)["kernels"][kernel]["hbm_bytes"])
     except Exception:
         return None
@@ -191,7 +191,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4),
-                         "traffic": measured_traffic("chunk_bwd_kernel" if dom_name == "backward" else "chunk_fwd_kernel")
+                         "traffic": measured_traffic("chunk_bwd16_kernel" if dom_name == "backward" else "chunk_fwd_kernel")
                          if args.workload == "wkv6" else None,
                          "algorithmic_bytes_per_launch": units * dom_b, "avg_ms": round(dom_ms, 4)},
             "roofline_step": {"bound": "hbm", "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -53,13 +53,14 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
     const bool producer = wid >= 4;
     const int wv = wid & 3;                                          // block (producer) / column tile (consumer)
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r);
-    const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k);
-    const bf16_t* const gv_ = reinterpret_cast<const bf16_t*>(a.v);
-    bf16_t* const gy_ = reinterpret_cast<bf16_t*>(a.y);
+    const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
+                                                              // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
+    const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
+    const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k) + base;
+    const bf16_t* const gv_ = reinterpret_cast<const bf16_t*>(a.v) + base;
+    bf16_t* const gy_ = reinterpret_cast<bf16_t*>(a.y) + base;
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
-    const long base = (long)b * a.T * a.C + (long)h * HEAD;
     const int ngrp = (ntok + GRP - 1) / GRP;
 
     if (producer) {
@@ -77,12 +78,12 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p < ntok) {
                     const int t = a.reverse ? ntok - 1 - p : p;
-                    const long idx = base + (long)t * a.C + 4 * c4;
+                    const unsigned idx = (unsigned)(t * a.C + 4 * c4);
                     if constexpr (!STATE_ONLY) pr[tt] = *reinterpret_cast<const uint2*>(gr_ + idx);
                     pk[tt] = *reinterpret_cast<const uint2*>(gk_ + idx);
                     pv[tt] = *reinterpret_cast<const uint2*>(gv_ + idx);
-                    if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + idx);
-                    else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + idx);
+                    if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + base + idx);
+                    else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + base + idx);
                 }
             }
         };
@@ -271,17 +272,17 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                         const bool valid = p < ntok;
                         const int pc = valid ? p : 0;                    // padding lanes still form a legal address
                         const int t = a.reverse ? ntok - 1 - pc : pc;
-                        const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
+                        const unsigned idx = (unsigned)(t * a.C + 16 * wv + 4 * g);
                         float o[4] = {yt[0] + yi[0], yt[1] + yi[1], yt[2] + yi[2], yt[3] + yi[3]};
                         if constexpr (ACC) {
                             float old[4];
-                            if (a.y_f32) io4<float>::load(a.y_f32 + idx, old);
+                            if (a.y_f32) io4<float>::load(a.y_f32 + base + idx, old);
                             else io4<bf16_t>::load(gy_ + idx, old);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) o[q] += old[q];
                         }
                         if (valid) {
-                            if (!ACC && a.y_f32) io4<float>::store(a.y_f32 + idx, o);
+                            if (!ACC && a.y_f32) io4<float>::store(a.y_f32 + base + idx, o);
                             else io4<bf16_t>::store(gy_ + idx, o);
                         }
                     }
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
     if (!STATE_ONLY && !ACC && a.zero_tail) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += 32)
-            io4<bf16_t>::store(gy_ + base + (long)t * a.C + 4 * (tid & 15), z);
+            io4<bf16_t>::store(gy_ + (unsigned)(t * a.C + 4 * (tid & 15)), z);
     }
 }
 

@@ -105,17 +105,18 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
     const int role = wid >> 2;                                           // 0 R, 1 K, 2 J0, 3 J1; channel quarter in phase P
     const int wv = wid & 3;                                              // tile owned in phase C, block prepared in phase P
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r);
-    const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k);
-    const bf16_t* const gv_ = reinterpret_cast<const bf16_t*>(a.v);
-    const bf16_t* const ggy = reinterpret_cast<const bf16_t*>(a.gy);
-    bf16_t* const ogr = reinterpret_cast<bf16_t*>(a.gr);
-    bf16_t* const ogk = reinterpret_cast<bf16_t*>(a.gk);
-    bf16_t* const ogv = reinterpret_cast<bf16_t*>(a.gv);
-    bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw);
+    const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
+                                                              // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
+    const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
+    const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k) + base;
+    const bf16_t* const gv_ = reinterpret_cast<const bf16_t*>(a.v) + base;
+    const bf16_t* const ggy = reinterpret_cast<const bf16_t*>(a.gy) + base;
+    bf16_t* const ogr = reinterpret_cast<bf16_t*>(a.gr) + base;
+    bf16_t* const ogk = reinterpret_cast<bf16_t*>(a.gk) + base;
+    bf16_t* const ogv = reinterpret_cast<bf16_t*>(a.gv) + base;
+    bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw) + base;
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
-    const long base = (long)b * a.T * a.C + (long)h * HEAD;
     const int nstmax = (a.T + STG - 1) / STG;
     const int nst = (ntok + STG - 1) / STG;
     int* const flags = reinterpret_cast<int*>(smem + OFF_FLAG);
@@ -137,13 +138,13 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
         pe = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < ntok) {
             const int t = a.reverse ? ntok - 1 - p : p;
-            const long idx = base + (long)t * a.C + ch0;
+            const unsigned idx = (unsigned)(t * a.C + ch0);
             pr = *reinterpret_cast<const uint2*>(gr_ + idx);
             pk = *reinterpret_cast<const uint2*>(gk_ + idx);
             pv = *reinterpret_cast<const uint2*>(gv_ + idx);
             pg = *reinterpret_cast<const uint2*>(ggy + idx);
-            if constexpr (W_RAW) pw = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + idx);
-            else pe = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + idx);
+            if constexpr (W_RAW) pw = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + base + idx);
+            else pe = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + base + idx);
         }
     };
 
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                     const int p = st * STG + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
-                        const long idx = base + (long)t * a.C + ch;
+                        const unsigned idx = (unsigned)(t * a.C + ch);
                         if (a.accumulate) {
                             float o1[4];
                             io4<bf16_t>::load(ogr + idx, o1);
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                     const int p = st * STG + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
-                        const long idx = base + (long)t * a.C + ch;
+                        const unsigned idx = (unsigned)(t * a.C + ch);
                         if (a.accumulate) {
                             float o2[4];
                             io4<bf16_t>::load(ogk + idx, o2);
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                     }
                 }
             }
+#ifndef DBG_NOGW
             // ---- gw: needs a_t of the R wave that owns the same key rows
             while (__hip_atomic_load(flags + wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != st)
                 __builtin_amdgcn_s_sleep(1);
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                 const int p = st * STG + blk * BLK + x;
                 if (p < ntok) {
                     const int t = a.reverse ? ntok - 1 - p : p;
-                    const long idx = base + (long)t * a.C + ch;
+                    const unsigned idx = (unsigned)(t * a.C + ch);
                     if (a.accumulate) {
                         float o3[4];
                         io4<bf16_t>::load(ogw + idx, o3);
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                     io4<bf16_t>::store(ogw + idx, o_gw);
                 }
             }
+#endif
             TLAP(2)
             __syncthreads();
             TLAP(3)
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
                     const float4 o1 = part[((st & 1) * SBLK + blk) * 256];
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
-                        const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
+                        const unsigned idx = (unsigned)(t * a.C + 16 * wv + 4 * g);
                         float o[4] = {accs[blk][0] + o1.x, accs[blk][1] + o1.y, accs[blk][2] + o1.z, accs[blk][3] + o1.w};
                         if (a.accumulate) {
                             float old[4];
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd16_kernel(const ScanArgs a)
     if (a.zero_tail && !a.accumulate) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += 64) {
-            const long idx = base + (long)t * a.C + 4 * (tid & 15);
+            const unsigned idx = (unsigned)(t * a.C + 4 * (tid & 15));
             io4<bf16_t>::store(ogr + idx, z);
             io4<bf16_t>::store(ogk + idx, z);
             io4<bf16_t>::store(ogv + idx, z);

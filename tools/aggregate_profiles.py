@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 output of tools/collect_profiles.sh to the two small files kept under profiles/:
+<prefix>_kernel_stats.csv (the --stats table) and <prefix>_pmc.json (per-launch counter averages per kernel, with
+the HBM byte totals computed as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are KiB and FETCH_SIZE
+counts half of the bytes of a coalesced stream on gfx950)."""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+src, prefix = sys.argv[1], sys.argv[2]
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], prefix + "_kernel_stats.csv")
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        per_dispatch = defaultdict(float)
+        meta = {}
+        for row in csv.DictReader(fh):
+            key = (row["Dispatch_Id"], row["Counter_Name"])
+            per_dispatch[key] += float(row["Counter_Value"])
+            meta[row["Dispatch_Id"]] = row["Kernel_Name"]
+        for (d, c), v in per_dispatch.items():
+            acc[meta[d]][c].append(v)
+out = {"command": "tools/collect_profiles.sh (rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --steps 50 --warmup 10 --no-cpu; "
+                  "one run per counter group, FETCH_SIZE and WRITE_SIZE in separate runs)",
+       "note": "per-launch averages; FETCH_SIZE/WRITE_SIZE are KiB; read bytes = 2 * FETCH_SIZE * 1024 on gfx950", "kernels": {}}
+for k, cs in acc.items():
+    short = "chunk_fwd_kernel" if "chunk_fwd_kernel" in k else "chunk_bwd16_kernel" if "chunk_bwd16" in k else "chunk_bwd_kernel" if "chunk_bwd" in k else None
+    if short is None:
+        continue
+    e = out["kernels"].setdefault(short, {"counters": {}})
+    for c, vals in cs.items():
+        e["counters"][c] = round(sum(vals) / len(vals), 1)
+for e in out["kernels"].values():
+    c = e["counters"]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        e["hbm_read_bytes"] = int(2 * c["FETCH_SIZE"] * 1024)
+        e["hbm_write_bytes"] = int(c["WRITE_SIZE"] * 1024)
+        e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
+json.dump(out, open(prefix + "_pmc.json", "w"), indent=1)
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in out["kernels"].items()}, indent=1))
