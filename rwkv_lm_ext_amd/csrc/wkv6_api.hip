@@ -94,6 +94,7 @@ ScanArgs base_args(int B, int T, int C, int H, const void* r, const void* k, con
     a.r = r; a.k = k; a.v = v; a.w = w; a.u = u;
     a.wkind = (flags & WKV6_W_RAW) ? 1 : 0;
     a.use_u = 1;
+    a.ckpt_tok = ckpt_tok();
     return a;
 }
 
@@ -105,7 +106,7 @@ const char* wkv6_amd_version(void) { return "0.1"; }
 
 size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H)
 {
-    // scan path: one fp32 [B,T,C] array; chunked path: one fp32 64x64 state per 64-token group (>= the former)
+    // scan path: one fp32 [B,T,C] array; chunked path: one fp32 64x64 state per ckpt_tok() tokens and head
     const size_t scan = (size_t)B * T * C * sizeof(float);
     const size_t chunk = chunk_ckpt_floats(B, T, H) * sizeof(float);
     return align_up(scan > chunk ? scan : chunk);

@@ -12,7 +12,6 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int BLK = 16;                       // tokens per block
 constexpr int NBLK = 4;                       // blocks per group (= waves)
 constexpr int GRP = BLK * NBLK;               // 64 tokens per group
-constexpr int CKPT_TOK = 32;                  // the forward leaves an fp32 state checkpoint every CKPT_TOK tokens
 constexpr int RSB = 160;                      // bytes per staged token row (64 bf16 + 16 pad): ds_read_b128 row reads and
                                               // ds_read_b64_tr_b16 are both conflict-free at this stride (144 B is 2-way on both)
 constexpr int ARR = BLK * RSB;                // one operand array

@@ -41,7 +41,7 @@ using namespace chunk;
 constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 
 // STATE_ONLY: no outputs, only the state recurrence (first half of the self-contained backward).
-// With a.ckpt the state at the entry of every 32-token stage is dumped (fp32, register order:
+// With a.ckpt the state is dumped every a.ckpt_tok tokens (fp32, register order:
 // [wave][tile][lane][4]) for the backward kernel.
 // ACC: add into y (from a.y_f32 when given) instead of overwriting -- the reverse half of wkv6_bi.
 template <bool W_RAW, bool STATE_ONLY, bool ACC>
@@ -227,8 +227,9 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
-                if (a.ckpt && !(blk & 1)) {   // state at the entry of every 32-token stage, for the backward kernel
-                    float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + CKPT_TOK - 1) / CKPT_TOK) + grp * (GRP / CKPT_TOK) + (blk >> 1)) * (HEAD * HEAD);
+                if (a.ckpt && (blk * BLK) % a.ckpt_tok == 0) {   // state every ckpt_tok (64 or 32) tokens, for the backward kernel
+                    float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) +
+                                                (grp * GRP + blk * BLK) / a.ckpt_tok) * (HEAD * HEAD);
 #pragma unroll
                     for (int it = 0; it < 4; ++it)
                         *reinterpret_cast<float4*>(ck + ((wv * 4 + it) * 64 + lane) * 4) =
@@ -351,7 +352,7 @@ hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st)
 
 size_t chunk_ckpt_floats(int B, int T, int H)
 {
-    return (size_t)B * H * ((T + CKPT_TOK - 1) / CKPT_TOK) * HEAD * HEAD;
+    return (size_t)B * H * ((T + ckpt_tok() - 1) / ckpt_tok()) * HEAD * HEAD;
 }
 
 }  // namespace wkv6

@@ -27,8 +27,6 @@
 //            and gv over i.  A row wave and a column wave share each SIMD, so their VALU/MFMA streams interleave.
 #include "wkv6_chunk.h"
 
-#include <cstdlib>
-
 namespace wkv6 {
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);
 hipError_t launch_chunk_bwd16(const ScanArgs& a, hipStream_t st);
@@ -48,7 +46,7 @@ constexpr int BOFF_E16M8 = BOFF_E16 + 256;
 constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float [2][16]  per-half sum_i r u k
 constexpr int BBLK_BYTES = BOFF_COEF + 128;
 
-constexpr int DPP_SHL1 = 0x101, DPP_SHL2 = 0x102, DPP_SHL4 = 0x104, DPP_SHL8 = 0x108;   // row_shl:n, zero fill
+#define WKV6_DPP_ACC(x, ctrl) asm("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
 
 __device__ __forceinline__ float pick4(const f4v& v, int s)
 {
@@ -78,17 +76,18 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
     const int wv = wid & 3;                                              // tile owned in phase C, block prepared in phase P
     const int half = wid >> 2;                                           // channel half prepared in phase P
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r);
-    const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k);
-    const bf16_t* const gv_ = reinterpret_cast<const bf16_t*>(a.v);
-    const bf16_t* const ggy = reinterpret_cast<const bf16_t*>(a.gy);
-    bf16_t* const ogr = reinterpret_cast<bf16_t*>(a.gr);
-    bf16_t* const ogk = reinterpret_cast<bf16_t*>(a.gk);
-    bf16_t* const ogv = reinterpret_cast<bf16_t*>(a.gv);
-    bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw);
+    const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
+                                                              // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
+    const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
+    const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k) + base;
+    const bf16_t* const gv_ = reinterpret_cast<const bf16_t*>(a.v) + base;
+    const bf16_t* const ggy = reinterpret_cast<const bf16_t*>(a.gy) + base;
+    bf16_t* const ogr = reinterpret_cast<bf16_t*>(a.gr) + base;
+    bf16_t* const ogk = reinterpret_cast<bf16_t*>(a.gk) + base;
+    bf16_t* const ogv = reinterpret_cast<bf16_t*>(a.gv) + base;
+    bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw) + base;
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
-    const long base = (long)b * a.T * a.C + (long)h * HEAD;
 
     // ---- phase-P role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block wv
     const int c8i = lane & 7, tq = lane >> 3;
@@ -106,13 +105,13 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
             pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < ntok) {
                 const int t = a.reverse ? ntok - 1 - p : p;
-                const long idx = base + (long)t * a.C + ch0;
+                const unsigned idx = (unsigned)(t * a.C + ch0);
                 pr[tt] = *reinterpret_cast<const uint2*>(gr_ + idx);
                 pk[tt] = *reinterpret_cast<const uint2*>(gk_ + idx);
                 pv[tt] = *reinterpret_cast<const uint2*>(gv_ + idx);
                 pg[tt] = *reinterpret_cast<const uint2*>(ggy + idx);
-                if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + idx);
-                else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + idx);
+                if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + base + idx);
+                else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + base + idx);
             }
         }
     };
@@ -139,7 +138,11 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                 cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + lws[tt][c];
                 // gw multiplier: the true lw, times d_true / d_clamped where the clamp is active (the algebra yields the
                 // exact gradient of the clamped model, d_clamped * X; the true one is d_true * X)
-                lwe[c] = valid ? lw[c] * __expf(fminf(lw[c] - LW_MIN, 0.f)) : 0.f;
+                lwe[c] = valid ? lw[c] : 0.f;
+            }
+            if (__builtin_amdgcn_ballot_w64(lwe[0] < LW_MIN || lwe[1] < LW_MIN || lwe[2] < LW_MIN || lwe[3] < LW_MIN)) {   // rare
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lwe[c] *= __expf(fminf(lwe[c] - LW_MIN, 0.f));
             }
             float part = 0.f;
 #pragma unroll
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             {   // group-entry forward state (dumped in the forward kernel's register order)
-                const float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + CKPT_TOK - 1) / CKPT_TOK) + grp * (GRP / CKPT_TOK)) * (HEAD * HEAD);
+                const float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) + grp * (GRP / a.ckpt_tok)) * (HEAD * HEAD);
                 // element S[i = 16wv + x][j]: forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), reg i&3
                 const int i_ = 16 * wv + x;
                 const int fit = 2 * (i_ >> 5) + ((i_ >> 2) & 1), fg = (i_ >> 3) & 3, fq = i_ & 3;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     const int p = grp * GRP + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
-                        const long idx = base + (long)t * a.C + ch;
+                        const unsigned idx = (unsigned)(t * a.C + ch);
                         if (a.accumulate) {
                             float o1[4];
                             io4<bf16_t>::load(ogr + idx, o1);
@@ -404,11 +407,11 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                         o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
                         const float bt = kv[q] * dk;
                         const float dl = at[blk][q] - bt;
-                        float sfx = dl;                           // inclusive suffix sum over the later tokens of the row
-                        sfx += dpp_mov<DPP_SHL1>(sfx);
-                        sfx += dpp_mov<DPP_SHL2>(sfx);
-                        sfx += dpp_mov<DPP_SHL4>(sfx);
-                        sfx += dpp_mov<DPP_SHL8>(sfx);
+                        float sfx = dl;                           // inclusive suffix sum over the later tokens of the row:
+                        WKV6_DPP_ACC(sfx, "row_shl:1");           // one v_add_f32_dpp per step (lanes without a source keep
+                        WKV6_DPP_ACC(sfx, "row_shl:2");           // their value: DPP disables them)
+                        WKV6_DPP_ACC(sfx, "row_shl:4");
+                        WKV6_DPP_ACC(sfx, "row_shl:8");
                         const float total = __shfl(sfx, lane & 48);
                         o_gw[q] = (Rc[q] + (sfx - dl) - bt) * lwv[q];
                         Rc[q] += total;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     const int p = grp * GRP + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
-                        const long idx = base + (long)t * a.C + ch;
+                        const unsigned idx = (unsigned)(t * a.C + ch);
                         if (a.accumulate) {
                             float o2[4], o3[4];
                             io4<bf16_t>::load(ogk + idx, o2);
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     const int p = grp * GRP + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
-                        const long idx = base + (long)t * a.C + 16 * wv + 4 * g;
+                        const unsigned idx = (unsigned)(t * a.C + 16 * wv + 4 * g);
                         float o[4] = {acc[0], acc[1], acc[2], acc[3]};
                         if (a.accumulate) {
                             float old[4];
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
     if (a.zero_tail && !a.accumulate) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += 32) {
-            const long idx = base + (long)t * a.C + 4 * (tid & 15);
+            const unsigned idx = (unsigned)(t * a.C + 4 * (tid & 15));
             io4<bf16_t>::store(ogr + idx, z);
             io4<bf16_t>::store(ogk + idx, z);
             io4<bf16_t>::store(ogv + idx, z);
@@ -604,8 +607,7 @@ hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
         sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
         if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
     }
-    static const bool use8 = std::getenv("WKV6_BWD8") != nullptr;     // A/B switch: the 8-wave kernel
-    if (!use8) return launch_chunk_bwd16(a, st);
+    if (use_bwd16()) return launch_chunk_bwd16(a, st);                // WKV6_BWD16=1: the 16-wave staged kernel (A/B runs)
     return a.wkind ? launch_bwd_variant<true>(a, st) : launch_bwd_variant<false>(a, st);
 }
 

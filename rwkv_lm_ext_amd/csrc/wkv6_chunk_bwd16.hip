@@ -56,7 +56,7 @@ constexpr int BOFF_E16 = BOFF_E8 + 256;
 constexpr int BOFF_E16M8 = BOFF_E16 + 256;
 constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float [4][16]  per-quarter sum_i r u k
 constexpr int BBLK_BYTES = BOFF_COEF + 256;
-constexpr int STG = CKPT_TOK;                                          // tokens per stage (= forward checkpoint spacing)
+constexpr int STG = 32;                                                // tokens per stage (= forward checkpoint spacing in this mode)
 constexpr int SBLK = STG / BLK;                                        // blocks per stage
 constexpr int BUF_BYTES = SBLK * BBLK_BYTES;                           // one stage image; two of them
 constexpr int OFF_PART = 2 * BUF_BYTES;                                // float4 [2][SBLK][4][64]  J1's partial gv tiles, by stage parity
@@ -657,6 +657,7 @@ template <bool W_RAW> hipError_t launch_bwd16_variant(const ScanArgs& a, hipStre
 
 hipError_t launch_chunk_bwd16(const ScanArgs& a, hipStream_t st)
 {
+    if (a.ckpt_tok != STG) return hipErrorInvalidValue;
     return a.wkind ? launch_bwd16_variant<true>(a, st) : launch_bwd16_variant<false>(a, st);
 }
 

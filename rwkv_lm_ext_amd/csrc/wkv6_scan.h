@@ -18,9 +18,19 @@
 // They are the reference-exact path (any T >= 1, any decay magnitude, optional initial / final
 // state, either time direction, per-row lengths).
 #pragma once
+#include <cstdlib>
 #include "wkv6_common.h"
 
 namespace wkv6 {
+
+// The chunked forward leaves an fp32 state checkpoint every ckpt_tok() tokens for the backward: every 64-token group for
+// the default 8-wave backward, every 32-token stage for the 16-wave staged backward (WKV6_BWD16=1 in the environment).
+inline bool use_bwd16()
+{
+    static const bool v = std::getenv("WKV6_BWD16") != nullptr;
+    return v;
+}
+inline int ckpt_tok() { return use_bwd16() ? 32 : 64; }
 
 struct ScanArgs {
     int B, T, C, H;
@@ -39,6 +49,7 @@ struct ScanArgs {
     void* gs;                         // [B,H,N,N] per-batch dL/dS0, I/O type (null: skip)
     float* aux;                       // [B,T,C] fp32 scratch carrying a_t from sweep S to sweep G
     float* ckpt;                      // chunked path: [B*H][ceil(T/64)][4096] fp32 group-entry states (state pass -> backward)
+    int ckpt_tok;                     // tokens between checkpoints (32 or 64)
     int ckpt_valid;                   // backward: ckpt was filled by the forward, skip the state pass
     const int* lens;                  // per-batch number of tokens to scan (null: T)
     int reverse;                      // 1: scan tokens lens-1 .. 0
