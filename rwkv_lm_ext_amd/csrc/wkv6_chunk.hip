@@ -231,9 +231,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                     float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) +
                                                 (grp * GRP + blk * BLK) / a.ckpt_tok) * (HEAD * HEAD);
 #pragma unroll
-                    for (int it = 0; it < 4; ++it)
-                        *reinterpret_cast<float4*>(ck + ((wv * 4 + it) * 64 + lane) * 4) =
-                            make_float4(St[it][0], St[it][1], St[it][2], St[it][3]);
+                    for (int it = 0; it < 4; ++it)   // streamed: written once, read once by the backward
+                        __builtin_nontemporal_store(St[it], reinterpret_cast<f4v*>(ck + ((wv * 4 + it) * 64 + lane) * 4));
                 }
                 // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
                 const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);

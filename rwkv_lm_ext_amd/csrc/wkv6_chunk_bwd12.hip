@@ -1,36 +1,15 @@
-// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O).  Companion of wkv6_chunk.hip; same block algebra.
-//
-// Per 16-token block (a = query token, b = key token, c_a exclusive cumulative log decay, S = forward state at
-// block entry, G = dL/d(state after the block)), with Rhat_a = r_a e^{c_a - c_8}, Khat_b = k_b e^{c_8 - c_{b+1}},
-// fR_a = e^{c_a - c_8}, fK_b = e^{c_8 - c_{b+1}}, E8 = e^{c_8}, E16 = e^{c_16}, E16m8 = e^{c_16 - c_8}:
-//   dA[a][b]  = gy_a . v_b                         (b < a),      vg_a = gy_a . v_a
-//   gv_b      = sum_{a>b} A[a][b] gy_a + (sum_i r_b u k_b) gy_b + sum_i Khat_b[i] (E16m8 (.) G)[i][:]
-//   dq_a      = fR_a (.) ( sum_{b<a} dA[a][b] Khat_b + (E8 (.) S) gy_a )        gr_a = dq_a + vg_a u (.) k_a
-//   dk_b      = fK_b (.) ( sum_{a>b} dA[a][b] Rhat_a + (E16m8 (.) G) v_b )      gk_b = dk_b + vg_b u (.) r_b
-//   G_entry   = E16 (.) G + E8 (.) sum_a Rhat_a gy_a^T
-//   gw_t      = lw_t (.) ( sum_{s>t} (r_s (.) dq_s - k_s (.) dk_s) - k_t (.) dk_t )   (suffix sum over the whole
-//               sequence; identity of fla/ops/rwkv6/recurrent_fuse.py:394-396, same as the scan kernels)
-//   gu       += vg_a r_a (.) k_a
-// i.e. the adjoint of cuda/wkv6_cuda.cu:44-57 (reference backward: cuda/wkv6_cuda.cu:63-227), re-associated.
-//
-// The forward states are needed in reverse order: the forward kernel (or, for a self-contained backward, its
-// state-only variant, launch_chunk_state_pass) dumps the state at the entry of every 64-token group (fp32) into
-// the workspace; this kernel walks the groups backwards, rebuilds the three intermediate block states of a group
-// in registers and then processes its four blocks in reverse.
-//
-// One 512-thread workgroup (8 wave64) per (batch, head), one barrier pair per group:
-//   phase P (all 8 waves): waves w and w+4 turn the two channel halves of block w into operands in LDS
-//            (lane = 4 channels x 2 tokens);
-//   phase C: "row" waves 0..3 own key rows [16w,16w+16): forward states and G with lane = key row; they produce
-//            gr, gk, gw, gu.  "column" waves 4..7 own value columns [16w,16w+16): G with lane = value column;
-//            they produce the scores, gv and gs.  G is kept in both orientations because gk contracts it over j
-//            and gv over i.  A row wave and a column wave share each SIMD, so their VALU/MFMA streams interleave.
+// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O), 12-wave staged version (the default; WKV6_BWD=8 / 16 select the others).  Block algebra, row and
+// column roles exactly as in wkv6_chunk_bwd.hip; what changes is the schedule.  In the 8-wave kernel a third of every
+// 64-token group is "phase P": all waves prepare operands (a long exp -> prefix -> exp -> split dependency chain at
+// ~30 % issue utilisation) and then meet at a barrier before any MFMA work starts.  Here
+//   * the unit of work is a 32-token stage (two blocks), the LDS image is double-buffered, one barrier per stage;
+//   * four dedicated producer waves (one per SIMD; wave = block x channel half, lane = 4 channels x 2 tokens) prepare
+//     stage s-1 into the other buffer and issue the global loads of stage s-2 while
+//   * the four row waves and four column waves work on stage s (three waves per SIMD, <= 168 VGPRs);
+//   * the forward leaves a state checkpoint every 32 tokens, so a row wave rebuilds one block state per stage.
 #include "wkv6_chunk.h"
 
 namespace wkv6 {
-hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);
-hipError_t launch_chunk_bwd16(const ScanArgs& a, hipStream_t st);
-hipError_t launch_chunk_bwd12(const ScanArgs& a, hipStream_t st);
 
 namespace {
 
@@ -46,6 +25,8 @@ constexpr int BOFF_E16 = BOFF_E8 + 256;
 constexpr int BOFF_E16M8 = BOFF_E16 + 256;
 constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float [2][16]  per-half sum_i r u k
 constexpr int BBLK_BYTES = BOFF_COEF + 128;
+constexpr int STG = 32, SBLK = STG / BLK;                             // tokens / blocks per stage
+constexpr int BUF_BYTES = SBLK * BBLK_BYTES;                           // one stage image; two of them
 
 #define WKV6_DPP_ACC(x, ctrl) asm("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
 
@@ -68,14 +49,14 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 }
 
 template <bool W_RAW>
-__global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
+__global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // [NBLK][BBLK_BYTES]
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][BBLK_BYTES]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool rowrole = wid < 4;
-    const int wv = wid & 3;                                              // tile owned in phase C, block prepared in phase P
-    const int half = wid >> 2;                                           // channel half prepared in phase P
+    const bool rowrole = wid < 4, producer = wid >= 8;
+    const int wv = wid & 3;                                              // tile owned by a row / column wave
+    const int pb = wid & 1, half = (wid >> 1) & 1;                       // producer: block of the stage, channel half
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
                                                               // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
@@ -90,7 +71,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
 
-    // ---- phase-P role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block wv
+    // ---- producer role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block pb
     const int c8i = lane & 7, tq = lane >> 3;
     const int ch0 = 32 * half + 4 * c8i;
     float uu[4] = {0.f, 0.f, 0.f, 0.f};
@@ -98,10 +79,10 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
 
     uint2 pr[2], pk[2], pv[2], pg[2], pw[2];
     float4 pe[2];
-    auto load_group = [&](int grp) {
+    auto load_group = [&](int grp) {   // grp = stage index here
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const int p = grp * GRP + wv * BLK + 2 * tq + tt;
+            const int p = grp * STG + pb * BLK + 2 * tq + tt;
             pr[tt] = pk[tt] = pv[tt] = pg[tt] = pw[tt] = make_uint2(0u, 0u);
             pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < ntok) {
@@ -118,11 +99,11 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
     };
 
     auto prep_group = [&](int grp) {
-        char* const bb = smem + wv * BBLK_BYTES;
+        char* const bb = smem + (grp & 1) * BUF_BYTES + pb * BBLK_BYTES;
         float r[2][4], k[2][4], cs[2][4], lws[2][4];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const bool valid = grp * GRP + wv * BLK + 2 * tq + tt < ntok;
+            const bool valid = grp * STG + pb * BLK + 2 * tq + tt < ntok;
             r[tt][0] = bf_lo(pr[tt].x); r[tt][1] = bf_hi(pr[tt].x); r[tt][2] = bf_lo(pr[tt].y); r[tt][3] = bf_hi(pr[tt].y);
             k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
             float lw[4];
@@ -210,23 +191,39 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
     const int x = lane & 15, g = lane >> 4;
     int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);          // transposed read, natural columns (own tile)
     int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);          // transposed read, tile-labelled columns: + tile_tr(t)
-    const int ngrp = (ntok + GRP - 1) / GRP;
-    if (ngrp > 0) load_group(ngrp - 1);
-
+    const int ngrp = (ntok + STG - 1) / STG;                      // stages
+    const int nstmax = (a.T + STG - 1) / STG;
+    if (producer) {
+        // =============== producers: operands of stage s-1 into the other buffer while stage s is consumed =====
+        if (ngrp > 0) {
+            load_group(ngrp - 1);
+            prep_group(ngrp - 1);
+            if (ngrp > 1) load_group(ngrp - 2);
+        }
+        __syncthreads();
+        for (int grp = ngrp - 1; grp >= 0; --grp) {
+            if (grp > 0) {
+                prep_group(grp - 1);
+                if (grp > 1) load_group(grp - 2);
+            }
+            __syncthreads();
+        }
+    } else
     if (rowrole) {
         // =============== key rows [16wv, 16wv+16): gr, gk, gw, gu ==========================================
         // ST[blk][jt][q] = S_entry(blk)[i = 16wv + x][j = tile_ch(jt) + 8g + q]   (transposed tiles: lane = key row)
         // GI[jt][q]      = G[i = 16wv + x][j = tile_ch(jt) + 8g + q]
         float ue[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
-        f4v ST[4][4], GI[4];
+        f4v ST[SBLK][4], GI[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) GI[t] = f4v{0.f, 0.f, 0.f, 0.f};
         float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
 
+        __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
-            {   // group-entry forward state (dumped in the forward kernel's register order)
-                const float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) + grp * (GRP / a.ckpt_tok)) * (HEAD * HEAD);
+            {   // stage-entry forward state (dumped in the forward kernel's register order)
+                const float* const ck = a.ckpt + ((long)blockIdx.x * nstmax + grp) * (HEAD * HEAD);
                 // element S[i = 16wv + x][j]: forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), reg i&3
                 const int i_ = 16 * wv + x;
                 const int fit = 2 * (i_ >> 5) + ((i_ >> 2) & 1), fg = (i_ >> 3) & 3, fq = i_ & 3;
@@ -241,16 +238,14 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
                 }
             }
-            prep_group(grp);
-            __syncthreads();
             asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this iteration below the barrier
-            if (grp > 0) load_group(grp - 1);
+            const char* const buf = smem + (grp & 1) * BUF_BYTES;
 
-            // ---- rebuild the entry states of blocks 1..3:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
+            // ---- rebuild the entry state of block 1:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
 #pragma unroll
-            for (int blk = 0; blk < NBLK - 1; ++blk) {
+            for (int blk = 0; blk < SBLK - 1; ++blk) {
                 {
-                    const char* const bb = smem + blk * BBLK_BYTES;
+                    const char* const bb = buf + blk * BBLK_BYTES;
                     const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
                     const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
                     const float e16 = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
@@ -270,11 +265,11 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
             //      Four independent blocks => many instructions in flight.
-            f4v ackp[NBLK];
-            float at[NBLK][4], vgs[NBLK];
+            f4v ackp[SBLK];
+            float at[SBLK][4], vgs[SBLK];
 #pragma unroll
-            for (int blk = NBLK - 1; blk >= 0; --blk) {
-                const char* const bb = smem + blk * BBLK_BYTES;
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                const char* const bb = buf + blk * BBLK_BYTES;
                 f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
                 b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: also the B operand of accr
 #pragma unroll
@@ -343,7 +338,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                         gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
                         at[blk][q] = rv[q] * dq;
                     }
-                    const int p = grp * GRP + blk * BLK + x;
+                    const int p = grp * STG + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
                         const unsigned idx = (unsigned)(t * a.C + ch);
@@ -359,8 +354,8 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
             }
             // ---- chain: only the work that needs G
 #pragma unroll
-            for (int blk = NBLK - 1; blk >= 0; --blk) {
-                const char* const bb = smem + blk * BBLK_BYTES;
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                const char* const bb = buf + blk * BBLK_BYTES;
                 const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
                 const float e16x = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
                 const float e16m8x = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
@@ -417,7 +412,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                         o_gw[q] = (Rc[q] + (sfx - dl) - bt) * lwv[q];
                         Rc[q] += total;
                     }
-                    const int p = grp * GRP + blk * BLK + x;
+                    const int p = grp * STG + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
                         const unsigned idx = (unsigned)(t * a.C + ch);
@@ -452,20 +447,19 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
         f4v GJ[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) GJ[t] = f4v{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
-            prep_group(grp);
-            __syncthreads();
             asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this iteration below the barrier
-            if (grp > 0) load_group(grp - 1);
+            const char* const buf = smem + (grp & 1) * BUF_BYTES;
             // ---- pre-phase: everything that does not depend on G, stage-major over the 4 blocks so that many
             //      independent LDS reads / MFMAs are in flight (blocks past the end of the sequence are neutral)
-            s4v gyT_w[NBLK], sc_hi[NBLK], sc_lo[NBLK];
-            f4v accp[NBLK], Og[NBLK][4];
+            s4v gyT_w[SBLK], sc_hi[SBLK], sc_lo[SBLK];
+            f4v accp[SBLK], Og[SBLK][4];
             {
-                f4v sc[NBLK];
+                f4v sc[SBLK];
 #pragma unroll
-                for (int blk = 0; blk < NBLK; ++blk) {
-                    const char* const bb = smem + blk * BBLK_BYTES;
+                for (int blk = 0; blk < SBLK; ++blk) {
+                    const char* const bb = buf + blk * BBLK_BYTES;
                     sc[blk] = f4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -479,8 +473,8 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     gyT_w[blk] = tr_read(bb + B_GY * ARR + troff + 32 * wv);      // gy[4g+e][16wv + x]
                 }
 #pragma unroll
-                for (int blk = 0; blk < NBLK; ++blk) {
-                    const char* const bb = smem + blk * BBLK_BYTES;
+                for (int blk = 0; blk < SBLK; ++blk) {
+                    const char* const bb = buf + blk * BBLK_BYTES;
                     const float4 cfa = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 16 * g);
                     const float4 cfb = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 64 + 16 * g);
                     const float cf[4] = {cfa.x + cfb.x, cfa.y + cfb.y, cfa.z + cfb.z, cfa.w + cfb.w};
@@ -496,8 +490,8 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                     sc_lo[blk] = __builtin_bit_cast(s4v, tl);
                 }
 #pragma unroll
-                for (int blk = 0; blk < NBLK; ++blk) {
-                    const char* const bb = smem + blk * BBLK_BYTES;
+                for (int blk = 0; blk < SBLK; ++blk) {
+                    const char* const bb = buf + blk * BBLK_BYTES;
                     f4v acc = {0.f, 0.f, 0.f, 0.f};               // gv^T[j][b], first part: sum_a gy[a][j] A[a][b]
                     acc = mfma16(gyT_w[blk], sc_hi[blk], acc);
                     acc = mfma16(gyT_w[blk], sc_lo[blk], acc);
@@ -515,8 +509,8 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
             }
             // ---- chain: only the work that needs G
 #pragma unroll
-            for (int blk = NBLK - 1; blk >= 0; --blk) {
-                const char* const bb = smem + blk * BBLK_BYTES;
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                const char* const bb = buf + blk * BBLK_BYTES;
                 f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -536,7 +530,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
                 }
                 acc += accp[blk];
                 {
-                    const int p = grp * GRP + blk * BLK + x;
+                    const int p = grp * STG + blk * BLK + x;
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
                         const unsigned idx = (unsigned)(t * a.C + 16 * wv + 4 * g);
@@ -574,7 +568,7 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
     }
     if (a.zero_tail && !a.accumulate) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = ntok + (tid >> 4); t < a.T; t += 32) {
+        for (int t = ntok + (tid >> 4); t < a.T; t += 48) {
             const unsigned idx = (unsigned)(t * a.C + 4 * (tid & 15));
             io4<bf16_t>::store(ogr + idx, z);
             io4<bf16_t>::store(ogk + idx, z);
@@ -584,33 +578,27 @@ __global__ __launch_bounds__(512) void chunk_bwd_kernel(const ScanArgs a)
     }
 }
 
-template <bool W_RAW> hipError_t launch_bwd_variant(const ScanArgs& a, hipStream_t st)
+template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)NBLK * BBLK_BYTES;
+    constexpr size_t lds = 2 * (size_t)BUF_BYTES;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_bwd_kernel<W_RAW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL((chunk_bwd_kernel<W_RAW>), dim3(a.B * a.H), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW>), dim3(a.B * a.H), dim3(768), lds, st, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
+hipError_t launch_chunk_bwd12(const ScanArgs& a, hipStream_t st)
 {
-    if (!a.ckpt_valid) {                   // self-contained backward: state pass first (same inputs, no outputs)
-        ScanArgs sp = a;
-        sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
-        if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
-    }
-    if (bwd_variant() == 12) return launch_chunk_bwd12(a, st);        // default
-    if (bwd_variant() == 16) return launch_chunk_bwd16(a, st);        // WKV6_BWD=16 / WKV6_BWD=8: alternatives for A/B runs
-    return a.wkind ? launch_bwd_variant<true>(a, st) : launch_bwd_variant<false>(a, st);
+    if (a.ckpt_tok != STG) return hipErrorInvalidValue;
+    return a.wkind ? launch_bwd12_variant<true>(a, st) : launch_bwd12_variant<false>(a, st);
 }
 
 }  // namespace wkv6

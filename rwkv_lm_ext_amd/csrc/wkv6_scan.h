@@ -23,14 +23,20 @@
 
 namespace wkv6 {
 
-// The chunked forward leaves an fp32 state checkpoint every ckpt_tok() tokens for the backward: every 64-token group for
-// the default 8-wave backward, every 32-token stage for the 16-wave staged backward (WKV6_BWD16=1 in the environment).
-inline bool use_bwd16()
+// Backward kernel of the chunked path: WKV6_BWD = 12 (default: 12-wave staged kernel with dedicated producer waves),
+// 8 (8-wave kernel, whole 64-token groups) or 16 (16-wave role-split staged kernel); the last two exist for A/B runs.
+// The chunked forward leaves an fp32 state checkpoint every ckpt_tok() tokens for it: every 32-token stage for the
+// staged kernels, every 64-token group for the 8-wave kernel.
+inline int bwd_variant()
 {
-    static const bool v = std::getenv("WKV6_BWD16") != nullptr;
+    static const int v = [] {
+        const char* e = std::getenv("WKV6_BWD");
+        const int x = e ? std::atoi(e) : 12;
+        return (x == 8 || x == 16) ? x : 12;
+    }();
     return v;
 }
-inline int ckpt_tok() { return use_bwd16() ? 32 : 64; }
+inline int ckpt_tok() { return bwd_variant() == 8 ? 64 : 32; }
 
 struct ScanArgs {
     int B, T, C, H;
