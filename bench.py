@@ -191,7 +191,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4),
-                         "traffic": measured_traffic("chunk_bwd_kernel" if dom_name == "backward" else "chunk_fwd_kernel")
+                         "traffic": measured_traffic("chunk_bwd12_kernel" if dom_name == "backward" else "chunk_fwd_kernel")
                          if args.workload == "wkv6" else None,
                          "algorithmic_bytes_per_launch": units * dom_b, "avg_ms": round(dom_ms, 4)},
             "roofline_step": {"bound": "hbm", "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

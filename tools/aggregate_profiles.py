@@ -25,7 +25,7 @@ out = {"command": "tools/collect_profiles.sh (rocprofv3 --kernel-trace --pmc <gr
                   "one run per counter group, FETCH_SIZE and WRITE_SIZE in separate runs)",
        "note": "per-launch averages; FETCH_SIZE/WRITE_SIZE are KiB; read bytes = 2 * FETCH_SIZE * 1024 on gfx950", "kernels": {}}
 for k, cs in acc.items():
-    short = "chunk_fwd_kernel" if "chunk_fwd_kernel" in k else "chunk_bwd16_kernel" if "chunk_bwd16" in k else "chunk_bwd_kernel" if "chunk_bwd" in k else None
+    short = next((n for n in ("chunk_fwd_kernel", "chunk_bwd12_kernel", "chunk_bwd16_kernel", "chunk_bwd_kernel") if n in k), None)
     if short is None:
         continue
     e = out["kernels"].setdefault(short, {"counters": {}})
