@@ -3,6 +3,9 @@
 #include "wkv6_scan.h"
 
 #include <mutex>
+#include <vector>
+#include <cstring>
+#include <cmath>
 
 using namespace wkv6;
 
@@ -306,19 +309,81 @@ int rwkv6_cuda_forward_fp32(int B, int T, int C, int H, float* state, const floa
     return rwkv6_infer(B, T, C, H, state, r, k, v, w, u, y, true, stream);
 }
 
+// Device self-test: (1) the cross-lane primitives, (2) the chunked MFMA kernels against the exact scan kernels on a
+// fixed pseudo-random problem (B=2, T=83, H=2: ragged last block and stage) -- catches a miscompiled or mis-scheduled
+// build (e.g. the mixed-shape MFMA accumulation hazard) at load time instead of in training.
+// Returns 0, a positive count of failed primitive checks, or WKV6_ESELFTEST.
 int wkv6_selftest(void* stream)
 {
-    int* d = nullptr;
-    if (hipMalloc(&d, sizeof(int)) != hipSuccess) return WKV6_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    int host = -1;
-    hipError_t e = hipMemsetAsync(d, 0, sizeof(int), st);
-    if (e == hipSuccess) e = launch_selftest(d, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(&host, d, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d);
-    if (e != hipSuccess) return (int)e;
-    return host;
+    {
+        int* d = nullptr;
+        if (hipMalloc(&d, sizeof(int)) != hipSuccess) return WKV6_EWORKSPACE;
+        int host = -1;
+        hipError_t e = hipMemsetAsync(d, 0, sizeof(int), st);
+        if (e == hipSuccess) e = launch_selftest(d, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&host, d, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d);
+        if (e != hipSuccess) return (int)e;
+        if (host != 0) return host;
+    }
+    const int B = 2, T = 83, H = 2, C = H * HEAD;
+    const size_t n = (size_t)B * T * C, nu = (size_t)C, ngu = (size_t)B * C;
+    const size_t ws = wkv6_backward_workspace_bytes(B, T, C, H);
+    // layout of one device allocation (bf16 elements): r k v w gy | y[2] gr[2] gk[2] gv[2] gw[2] | u | gu[2] ; then workspace
+    const size_t elems = 5 * n + 10 * n + nu + 2 * ngu;
+    const size_t bytes = align_up(elems * 2);
+    char* dev = nullptr;
+    if (hipMalloc(&dev, bytes + ws) != hipSuccess) return WKV6_EWORKSPACE;
+    std::vector<unsigned short> host(elems, 0);
+    unsigned lcg = 12345u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return ((lcg >> 8) & 0xffff) / 65536.0f - 0.5f; };   // U(-0.5, 0.5)
+    auto to_bf = [](float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); };
+    for (size_t i = 0; i < n; ++i) {
+        host[i] = to_bf(rnd());                      // r
+        host[n + i] = to_bf(rnd());                  // k
+        host[2 * n + i] = to_bf(rnd());              // v
+        host[3 * n + i] = to_bf(-6.f + 7.f * (rnd() + 0.5f));   // w in [-6, 1]
+        host[4 * n + i] = to_bf(rnd());              // gy
+    }
+    for (size_t i = 0; i < nu; ++i) host[15 * n + i] = to_bf(rnd());
+    bf16_t* const p = reinterpret_cast<bf16_t*>(dev);
+    hipError_t e = hipMemcpyAsync(dev, host.data(), elems * 2, hipMemcpyHostToDevice, st);
+    int rc = e == hipSuccess ? WKV6_OK : (int)e;
+    const unsigned base_flags = WKV6_W_RAW;
+    for (int alg = 0; alg < 2 && rc == WKV6_OK; ++alg) {   // 0: chunked, 1: scan
+        const unsigned fl = base_flags | (alg ? WKV6_ALGO_SCAN : 0u);
+        rc = wkv6_forward_ex(B, T, C, H, p, p + n, p + 2 * n, p + 3 * n, p + 15 * n, nullptr, nullptr, p + (5 + alg) * n, fl, stream);
+        if (rc == WKV6_OK)
+            rc = wkv6_backward_ex(B, T, C, H, p, p + n, p + 2 * n, p + 3 * n, p + 15 * n, nullptr, p + 4 * n, p + (7 + alg) * n,
+                                  p + (9 + alg) * n, p + (11 + alg) * n, p + (13 + alg) * n, p + 15 * n + nu + alg * ngu, nullptr,
+                                  dev + bytes, ws, fl, stream);
+    }
+    if (rc == WKV6_OK) {
+        e = hipMemcpyAsync(host.data(), dev, elems * 2, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = (int)e;
+    }
+    (void)hipFree(dev);
+    if (rc != WKV6_OK) return rc;
+    auto bf = [&](size_t i) { unsigned u = (unsigned)host[i] << 16; float f; memcpy(&f, &u, 4); return f; };
+    auto differ = [&](size_t a0, size_t b0, size_t cnt, float ulps) {   // max |a-b| in bf16 ulps of the tensor scale
+        float scale = 0.f, diff = 0.f;
+        for (size_t i = 0; i < cnt; ++i) {
+            scale = fmaxf(scale, fabsf(bf(b0 + i)));
+            diff = fmaxf(diff, fabsf(bf(a0 + i) - bf(b0 + i)));
+        }
+        return !(diff <= ulps * scale * 0.0078125f);   // also catches NaN
+    };
+    int bad = 0;
+    bad += differ(5 * n, 6 * n, n, 2.f);          // y
+    bad += differ(7 * n, 8 * n, n, 2.f);          // gr
+    bad += differ(9 * n, 10 * n, n, 2.f);         // gk
+    bad += differ(11 * n, 12 * n, n, 2.f);        // gv
+    bad += differ(13 * n, 14 * n, n, 4.f);        // gw
+    bad += differ(15 * n + nu, 15 * n + nu + ngu, ngu, 2.f);   // gu
+    return bad ? WKV6_ESELFTEST : WKV6_OK;
 }
 
 }  // extern "C"
