@@ -296,6 +296,9 @@ static int rwkv6_infer(int B, int T, int C, int H, float* state, const void* r, 
     a.s0 = state; a.s_out = state;
     a.s0_bstride = (long)H * HEAD * HEAD;
     a.y = y;
+    // prefill-sized calls in bf16 go through the chunked MFMA kernel (log of the given decay, fp32 state I/O); decode
+    // (a few tokens) and fp32 I/O use the exact scan
+    if (!f32 && T >= 32) return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
     return to_rc(launch_scan_fwd(a, f32, (hipStream_t)stream));
 }
 int rwkv6_cuda_forward_bf16(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,

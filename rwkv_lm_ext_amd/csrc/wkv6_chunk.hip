@@ -101,6 +101,10 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                     lw[2] = -__expf(bf_lo(pw[tt].y)); lw[3] = -__expf(bf_hi(pw[tt].y));
                 } else {
                     lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
+                    if (a.wkind == 2) {   // the inference entry points pass the decay d = exp(-exp(w)) itself (cuda/rwkv6.cu:38)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) lw[c] = __logf(lw[c]);   // d = 0 -> -inf -> clamped below
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -210,9 +214,11 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             float t4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.s0)
-                io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.s0) + (long)b * a.s0_bstride +
-                                  ((long)h * HEAD + 16 * wv + x) * HEAD + tile_ch(it) + 8 * g, t4);
+            if (a.s0) {
+                const long so_ = (long)b * a.s0_bstride + ((long)h * HEAD + 16 * wv + x) * HEAD + tile_ch(it) + 8 * g;
+                if (a.state_f32) io4<float>::load(reinterpret_cast<const float*>(a.s0) + so_, t4);
+                else io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.s0) + so_, t4);
+            }
             St[it] = f4v{t4[0], t4[1], t4[2], t4[3]};
         }
         int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read, natural columns (this wave's V tile)
@@ -306,11 +312,12 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             __syncthreads();
         }
         if (a.s_out) {
-            bf16_t* const so = reinterpret_cast<bf16_t*>(a.s_out) + ((long)b * a.H + h) * HEAD * HEAD;
+            const long so_ = ((long)b * a.H + h) * HEAD * HEAD + (long)(16 * wv + x) * HEAD + 8 * g;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const float t4[4] = {St[it][0], St[it][1], St[it][2], St[it][3]};
-                io4<bf16_t>::store(so + (long)(16 * wv + x) * HEAD + tile_ch(it) + 8 * g, t4);
+                if (a.state_f32) io4<float>::store(reinterpret_cast<float*>(a.s_out) + so_ + tile_ch(it), t4);
+                else io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.s_out) + so_ + tile_ch(it), t4);
             }
         }
     }
@@ -339,14 +346,15 @@ template <bool W_RAW, bool STATE_ONLY, bool ACC> hipError_t launch_fwd_variant(c
 
 hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st)
 {
-    if (a.accumulate) return a.wkind ? launch_fwd_variant<true, false, true>(a, st) : launch_fwd_variant<false, false, true>(a, st);
-    return a.wkind ? launch_fwd_variant<true, false, false>(a, st) : launch_fwd_variant<false, false, false>(a, st);
+    const bool raw = a.wkind == 1;          // 0: fp32 ew = -exp(w), 1: raw w in bf16, 2: fp32 decay exp(-exp(w))
+    if (a.accumulate) return raw ? launch_fwd_variant<true, false, true>(a, st) : launch_fwd_variant<false, false, true>(a, st);
+    return raw ? launch_fwd_variant<true, false, false>(a, st) : launch_fwd_variant<false, false, false>(a, st);
 }
 
 // state recurrence only, dumping the group-entry states into a.ckpt (first half of the self-contained backward)
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st)
 {
-    return a.wkind ? launch_fwd_variant<true, true, false>(a, st) : launch_fwd_variant<false, true, false>(a, st);
+    return a.wkind == 1 ? launch_fwd_variant<true, true, false>(a, st) : launch_fwd_variant<false, true, false>(a, st);
 }
 
 size_t chunk_ckpt_floats(int B, int T, int H)

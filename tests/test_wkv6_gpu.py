@@ -422,3 +422,14 @@ def test_rwkv6_stateful_inference_kernel(ops, oracle, io):
     y, _ = RUN_RWKV_6(B2, 20, C, H, stb, *(dev(t, io) for t in (r, k, v, w, u)))
     check(y, yo, io, "rwkv6 batched y")
     assert max_norm_err(host(stb), so) <= F32_TOL
+    # prefill-sized call: bf16 goes through the chunked MFMA kernel (state stays fp32), then a short decode continues it
+    Tp = 300
+    r, k, v, w, u, _ = rand_inputs(58, 2, Tp + 3, H)
+    sb = (torch.randn(2, H, 64, 64, generator=g) * 0.5).numpy()
+    yo, so = oracle.forward(r, k, v, w, u, sb, return_state=True)
+    d = [dev(t, io) for t in (r, k, v, w, u)]
+    st2 = dev(sb, torch.float32)
+    y1, _ = RUN_RWKV_6(2, Tp, C, H, st2, *(t[:, :Tp].contiguous() for t in d[:4]), d[4])
+    y2, _ = RUN_RWKV_6(2, 3, C, H, st2, *(t[:, Tp:].contiguous() for t in d[:4]), d[4])
+    check(torch.cat([y1, y2], 1), yo, io, "rwkv6 prefill + decode y")
+    assert max_norm_err(host(st2), so) <= (F32_TOL if io == torch.float32 else 2e-4)   # chunked path: split-bf16 products
