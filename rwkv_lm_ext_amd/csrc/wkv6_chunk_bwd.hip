@@ -1,4 +1,5 @@
-// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O).  Companion of wkv6_chunk.hip; same block algebra.
+// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O), 8-wave version (WKV6_BWD=8; the default is the 12-wave staged
+// kernel in wkv6_chunk_bwd12.hip, which shares this file's roles and algebra).  Companion of wkv6_chunk.hip.
 //
 // Per 16-token block (a = query token, b = key token, c_a exclusive cumulative log decay, S = forward state at
 // block entry, G = dL/d(state after the block)), with Rhat_a = r_a e^{c_a - c_8}, Khat_b = k_b e^{c_8 - c_{b+1}},

@@ -1,5 +1,5 @@
-// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O), 12-wave staged version (the default; WKV6_BWD=8 / 16 select the others).  Block algebra, row and
-// column roles exactly as in wkv6_chunk_bwd.hip; what changes is the schedule.  In the 8-wave kernel a third of every
+// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O), 12-wave staged version (the default; WKV6_BWD=8 / 16 select the
+// others).  Block algebra, row and column roles exactly as in wkv6_chunk_bwd.hip; what changes is the schedule.  In the 8-wave kernel a third of every
 // 64-token group is "phase P": all waves prepare operands (a long exp -> prefix -> exp -> split dependency chain at
 // ~30 % issue utilisation) and then meet at a barrier before any MFMA work starts.  Here
 //   * the unit of work is a 32-token stage (two blocks), the LDS image is double-buffered, one barrier per stage;
