@@ -378,6 +378,27 @@ def test_chunk_backward_agrees_with_scan(ops):
         assert same >= 0.97 and rel <= 2.0 ** -7 * (2.02 if n == "gw" else 1.01), (n, same, rel)
 
 
+@pytest.mark.parametrize("T", [1, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 95, 97, 129])
+def test_chunked_kernels_at_block_and_stage_boundaries(ops, T):
+    """Sequence lengths around the 16-token block, 32-token stage and 64-token group boundaries, with an initial state:
+    the chunked forward / backward (checkpoint path included) against the exact scan kernels on the same inputs."""
+    B, H = 2, 2
+    r, k, v, w, u, gy = rand_inputs(300 + T, B, T, H, "init")
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(T)
+    s0 = dev((torch.randn(H, 64, 64, generator=g) * 0.5).numpy(), bf)
+    d = [dev(t, bf) for t in (r, k, v, w, u, gy)]
+    ck = ops.new_checkpoint(B, T, H * 64, H, "cuda")
+    yc = ops.forward_ex(*d[:5], H, s0=s0, ckpt=ck)
+    ys = ops.forward_ex(*d[:5], H, s0=s0, algo="scan")
+    oc = ops.backward_ex(*d, H, s0=s0, want_gs=True, ckpt=ck)
+    osn = ops.backward_ex(*d, H, s0=s0, want_gs=True, algo="scan")
+    for n, c, s_ in zip(("y", "gr", "gk", "gv", "gw", "gu", "gs"), (yc,) + tuple(oc), (ys,) + tuple(osn)):
+        c, s_ = host(c), host(s_)
+        scale = max(float(np.abs(s_).max()), 1e-3)
+        assert float(np.abs(c - s_).max()) <= (4.0 if n in ("gw", "gu", "gs") else 2.0) * 2.0 ** -8 * scale, (n, T)
+
+
 def test_forward_checkpoints_feed_backward(ops, oracle):
     """Training path: forward_ex(ckpt=) stores the per-group states, backward_ex(ckpt=) consumes them; results
     must be identical (bitwise) to the self-contained backward that recomputes them with its own state pass."""
