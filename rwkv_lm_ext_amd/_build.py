@@ -10,7 +10,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "librwkv6_amd.so")
-SOURCES = ["wkv6_scan.hip", "wkv6_chunk.hip", "wkv6_chunk_bwd.hip", "wkv6_chunk_bwd16.hip", "wkv6_chunk_bwd12.hip", "wkv6_api.hip"]
+SOURCES = ["wkv6_scan.hip", "wkv6_chunk.hip", "wkv6_chunk_bwd12.hip", "wkv6_api.hip"]
 HEADERS = ["wkv6_common.h", "wkv6_scan.h", "wkv6_chunk.h", os.path.join("..", "..", "include", "wkv6_amd.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -28,22 +28,36 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link librwkv6_amd.so.  Returns its path."""
-    if not force and not needs_build():
-        return LIB_PATH
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB_PATH
+    """Compile every HIP source for gfx950 and link librwkv6_amd.so.  Returns its path.
+
+    Safe under torchrun: an inter-process lock serialises the staleness check and the build, objects go to a private
+    temporary directory and the finished library is moved into place atomically, so another rank can never dlopen a
+    half-written file."""
+    import fcntl
+    import tempfile
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB_PATH
+            with tempfile.TemporaryDirectory(prefix="rwkv6_build_", dir=PKG_DIR) as tmp:
+                objs = []
+                for src in SOURCES:
+                    obj = os.path.join(tmp, src.replace(".hip", ".o"))
+                    cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd))
+                    subprocess.check_call(cmd)
+                    objs.append(obj)
+                out = os.path.join(tmp, "librwkv6_amd.so")
+                cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                os.replace(out, LIB_PATH)
+            return LIB_PATH
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 if __name__ == "__main__":

@@ -72,6 +72,26 @@ def load():
     return _lib
 
 
+_selftested = set()
+
+
+def selftest_once(device_index, stream_ptr):
+    """Run wkv6_selftest the first time a device is used (cross-lane primitives, then the chunked MFMA kernels against
+    the exact scan kernels): a mis-scheduled build fails loudly here instead of training silently wrong.
+    RWKV_AMD_NO_SELFTEST=1 skips it."""
+    if device_index in _selftested:
+        return
+    with _lock:
+        if device_index in _selftested:
+            return
+        if os.environ.get("RWKV_AMD_NO_SELFTEST", "0") != "1":
+            rc = _lib.wkv6_selftest(stream_ptr)
+            if rc != 0:
+                raise RuntimeError(f"librwkv6_amd.so failed its device self-test on cuda:{device_index} (code {rc}); "
+                                   "the build is unusable on this device")
+        _selftested.add(device_index)
+
+
 def check(rc, what):
     if rc != 0:
         msg = ERRORS.get(rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")

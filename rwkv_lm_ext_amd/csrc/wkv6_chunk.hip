@@ -331,13 +331,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 template <bool W_RAW, bool STATE_ONLY, bool ACC> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = 2 * (size_t)GRP_BYTES;
-    static bool configured = false;            // per instantiation; the attribute is per function, set once
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static LdsAttrOnce attr;                   // per instantiation and device
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), lds)) return e;
     hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), dim3(a.B * a.H), dim3(512), lds, st, a);
     return hipGetLastError();
 }

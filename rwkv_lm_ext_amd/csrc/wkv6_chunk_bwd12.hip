@@ -1,12 +1,29 @@
-// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O), 12-wave staged version (the default; WKV6_BWD=8 / 16 select the
-// others).  Block algebra, row and column roles exactly as in wkv6_chunk_bwd.hip; what changes is the schedule.  In the 8-wave kernel a third of every
-// 64-token group is "phase P": all waves prepare operands (a long exp -> prefix -> exp -> split dependency chain at
-// ~30 % issue utilisation) and then meet at a barrier before any MFMA work starts.  Here
-//   * the unit of work is a 32-token stage (two blocks), the LDS image is double-buffered, one barrier per stage;
+// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O): 12-wave staged kernel.  Companion of wkv6_chunk.hip.
+//
+// Per 16-token block (a = query token, b = key token, c_a exclusive cumulative log decay, S = forward state at
+// block entry, G = dL/d(state after the block)), with Rhat_a = r_a e^{c_a - c_8}, Khat_b = k_b e^{c_8 - c_{b+1}},
+// fR_a = e^{c_a - c_8}, fK_b = e^{c_8 - c_{b+1}}, E8 = e^{c_8}, E16 = e^{c_16}, E16m8 = e^{c_16 - c_8}:
+//   dA[a][b]  = gy_a . v_b                         (b < a),      vg_a = gy_a . v_a
+//   gv_b      = sum_{a>b} A[a][b] gy_a + (sum_i r_b u k_b) gy_b + sum_i Khat_b[i] (E16m8 (.) G)[i][:]
+//   dq_a      = fR_a (.) ( sum_{b<a} dA[a][b] Khat_b + (E8 (.) S) gy_a )        gr_a = dq_a + vg_a u (.) k_a
+//   dk_b      = fK_b (.) ( sum_{a>b} dA[a][b] Rhat_a + (E16m8 (.) G) v_b )      gk_b = dk_b + vg_b u (.) r_b
+//   G_entry   = E16 (.) G + E8 (.) sum_a Rhat_a gy_a^T
+//   gw_t      = lw_t (.) ( sum_{s>t} (r_s (.) dq_s - k_s (.) dk_s) - k_t (.) dk_t )   (suffix sum over the whole
+//               sequence; identity of fla/ops/rwkv6/recurrent_fuse.py:394-396, same as the scan kernels)
+//   gu       += vg_a r_a (.) k_a
+// i.e. the adjoint of cuda/wkv6_cuda.cu:44-57 (reference backward: cuda/wkv6_cuda.cu:63-227), re-associated.
+//
+// The forward states are needed in reverse order: the forward kernel (or, for a self-contained backward, its
+// state-only variant, launch_chunk_state_pass) dumps the state at the entry of every 32-token stage (fp32) into
+// the workspace; this kernel walks the stages backwards and rebuilds the second block state of a stage in registers.
+//
+// One 768-thread workgroup (12 wave64) per (batch, head), one barrier per stage:
+//   * "row" waves 0..3 own key rows [16w,16w+16): forward states and G with lane = key row; they produce gr, gk, gw, gu;
+//   * "column" waves 4..7 own value columns [16w,16w+16): G with lane = value column; they produce the scores, gv, gs.
+//     G is kept in both orientations because gk contracts it over j and gv over i;
 //   * four dedicated producer waves (one per SIMD; wave = block x channel half, lane = 4 channels x 2 tokens) prepare
-//     stage s-1 into the other buffer and issue the global loads of stage s-2 while
-//   * the four row waves and four column waves work on stage s (three waves per SIMD, <= 168 VGPRs);
-//   * the forward leaves a state checkpoint every 32 tokens, so a row wave rebuilds one block state per stage.
+//     stage s-1 into the other LDS buffer and issue the global loads of stage s-2 while stage s is consumed
+//     (three waves per SIMD, <= 168 VGPRs).
 #include "wkv6_chunk.h"
 
 namespace wkv6 {
@@ -582,22 +599,24 @@ template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStre
 {
     constexpr size_t lds = 2 * (size_t)BUF_BYTES;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static LdsAttrOnce attr;                   // per instantiation and device
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW>), lds)) return e;
     hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW>), dim3(a.B * a.H), dim3(768), lds, st, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_chunk_bwd12(const ScanArgs& a, hipStream_t st)
+hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // wkv6_chunk.hip
+
+hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
 {
     if (a.ckpt_tok != STG) return hipErrorInvalidValue;
+    if (!a.ckpt_valid) {                   // self-contained backward: state pass first (same inputs, no outputs)
+        ScanArgs sp = a;
+        sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
+        if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
+    }
     return a.wkind ? launch_bwd12_variant<true>(a, st) : launch_bwd12_variant<false>(a, st);
 }
 

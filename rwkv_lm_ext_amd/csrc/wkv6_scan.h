@@ -23,20 +23,24 @@
 
 namespace wkv6 {
 
-// Backward kernel of the chunked path: WKV6_BWD = 12 (default: 12-wave staged kernel with dedicated producer waves),
-// 8 (8-wave kernel, whole 64-token groups) or 16 (16-wave role-split staged kernel); the last two exist for A/B runs.
-// The chunked forward leaves an fp32 state checkpoint every ckpt_tok() tokens for it: every 32-token stage for the
-// staged kernels, every 64-token group for the 8-wave kernel.
-inline int bwd_variant()
-{
-    static const int v = [] {
-        const char* e = std::getenv("WKV6_BWD");
-        const int x = e ? std::atoi(e) : 12;
-        return (x == 8 || x == 16) ? x : 12;
-    }();
-    return v;
-}
-inline int ckpt_tok() { return bwd_variant() == 8 ? 64 : 32; }
+// The chunked forward leaves an fp32 state checkpoint every ckpt_tok() tokens for the chunked backward
+// (wkv6_chunk_bwd12.hip: one per 32-token stage).
+constexpr int CKPT_TOK = 32;
+inline int ckpt_tok() { return CKPT_TOK; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute is per device.
+struct LdsAttrOnce {
+    bool done[64] = {};
+    hipError_t ensure(const void* fn, size_t bytes)
+    {
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev)) return e;
+        if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+        if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)) return e;
+        if (dev >= 0 && dev < 64) done[dev] = true;
+        return hipSuccess;
+    }
+};
 
 struct ScanArgs {
     int B, T, C, H;
@@ -55,7 +59,7 @@ struct ScanArgs {
     void* gs;                         // [B,H,N,N] per-batch dL/dS0, I/O type (null: skip)
     float* aux;                       // [B,T,C] fp32 scratch carrying a_t from sweep S to sweep G
     float* ckpt;                      // chunked path: [B*H][ceil(T/64)][4096] fp32 group-entry states (state pass -> backward)
-    int ckpt_tok;                     // tokens between checkpoints (32 or 64)
+    int ckpt_tok;                     // tokens between checkpoints (CKPT_TOK)
     int ckpt_valid;                   // backward: ckpt was filled by the forward, skip the state pass
     const int* lens;                  // per-batch number of tokens to scan (null: T)
     int reverse;                      // 1: scan tokens lens-1 .. 0

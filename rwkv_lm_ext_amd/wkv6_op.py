@@ -49,6 +49,10 @@ def _check_tensors(B, T, C, H, named, dtype=torch.bfloat16):
             raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
     if C != H * HEAD_SIZE:
         raise RuntimeError(f"C ({C}) must equal H*{HEAD_SIZE} ({H * HEAD_SIZE})")   # reference: assert(H*_N_ == C)
+    _lib.load()
+    if dev.index not in _lib._selftested:
+        with torch.cuda.device(dev):
+            _lib.selftest_once(dev.index, _stream_ptr())
     return dev
 
 

@@ -1,0 +1,175 @@
+"""Parity of the DEFAULT (chunked MFMA, bf16 I/O) kernels at the shapes bench.py times -- BASELINE.json
+configs[1], [2] and [4] at full size.  The CPU oracle cannot run the whole problem in seconds, so every case
+checks (b, h) slices of the full-size result against the oracle (every (b, h) pair is an independent recurrence,
+cuda/wkv6_cuda.cu:11-12) and, over the whole tensor, the chunked kernels against the exact scan kernels.
+
+Tolerances: the suite's bf16 contract (tests/test_wkv6_gpu.py): rel-rms <= 1e-3 against RNE_bf16(oracle), <= 2 bf16
+ulps anywhere, >= 95 % of the significant elements correctly rounded.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bf16_report, max_norm_err
+
+pytestmark = pytest.mark.gpu
+
+BF16_RMS, BF16_ULPS, BF16_EXACT = 1e-3, 2.0, 0.95
+bf = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "the gpu suite needs a GPU"
+    from rwkv_lm_ext_amd import wkv6_op
+    return wkv6_op
+
+
+def host(t):
+    return t.detach().float().cpu().numpy()
+
+
+def check_bf16(out, ref, what, rms_tol=BF16_RMS, ulps_tol=BF16_ULPS, exact=BF16_EXACT):
+    floor = 0.1 if what.split()[-1].startswith("gw") else 1e-3
+    rms, off, ulps = bf16_report(host(out) if isinstance(out, torch.Tensor) else out, ref, floor=floor)
+    assert rms <= rms_tol and ulps <= ulps_tol and off <= 1 - exact, \
+        f"{what}: bf16 rel-rms {rms:.2e}, max {ulps:.2f} ulp, {off * 100:.1f}% not correctly rounded"
+
+
+def synth(B, T, H, seed=0):
+    """bench.py's synthetic inputs: init-ramp decays."""
+    C = H * 64
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r, k, v = (torch.randn(B, T, C, device="cuda", generator=g).mul_(0.5).to(bf) for _ in range(3))
+    ramp = torch.tensor([-6 + 5 * (n / (C - 1)) ** (0.7 + 1.3 * 0.5) for n in range(C)], device="cuda")
+    w = (ramp.view(1, 1, C) + 0.1 * torch.randn(B, T, C, device="cuda", generator=g)).to(bf)
+    u = (torch.randn(H, 64, device="cuda", generator=g) * 0.3).to(bf)
+    gy = torch.randn(B, T, C, device="cuda", generator=g).to(bf)
+    return r, k, v, w, u, gy
+
+
+def head_slice(b, h):
+    return (slice(b, b + 1), slice(None), slice(64 * h, 64 * h + 64))
+
+
+def agree_with_scan(chunk, scan, what, exact=0.97, ulps=1.0):
+    """chunked vs exact-scan kernels over the whole tensor: identical bf16 value on >= 97 % of the significant
+    elements, never more than `ulps` bf16 ulps apart."""
+    a, b = host(chunk).astype(np.float64), host(scan).astype(np.float64)
+    scale = np.abs(b).max()
+    big = np.abs(b) >= 1e-2 * scale
+    same = float(np.mean(a[big] == b[big]))
+    ulp = np.maximum(np.abs(b), 1e-2 * scale) * 2.0 ** -7
+    worst = float((np.abs(a - b) / ulp).max())
+    assert same >= exact and worst <= ulps, f"{what}: {same * 100:.2f}% identical, worst {worst:.2f} ulp"
+
+
+def test_config2_chunked_fwd_bwd_vs_oracle_slices(ops, oracle):
+    """BASELINE configs[1]: B=8, T=4096, C=2048, H=32, bf16, init decays -- the kernels and launch shape bench.py
+    times (256 workgroups, forward emitting checkpoints, backward consuming them)."""
+    B, T, H = 8, 4096, 32
+    C = H * 64
+    r, k, v, w, u, gy = synth(B, T, H)
+    ckpt = ops.new_checkpoint(B, T, C, H, r.device)
+    y = ops.forward_ex(r, k, v, w, u, H, ckpt=ckpt)
+    gr, gk, gv, gw, gu, _ = ops.backward_ex(r, k, v, w, u, gy, H, ckpt=ckpt)
+    y_nc = ops.forward_ex(r, k, v, w, u, H)                         # the forward without checkpoints: same values
+    agree_with_scan(y_nc, y, "y without checkpoints", exact=0.999)
+    gr2, gk2, gv2, gw2, gu2, _ = ops.backward_ex(r, k, v, w, u, gy, H)   # self-contained backward (own state pass)
+    for a, b_, n in ((gr, gr2, "gr"), (gk, gk2, "gk"), (gv, gv2, "gv"), (gw, gw2, "gw")):
+        agree_with_scan(b_, a, n + " (self-contained backward)", exact=0.999)
+    for (b, h) in ((0, 0), (7, 31), (3, 16), (5, 17), (2, 9)):
+        sl = head_slice(b, h)
+        rs, ks, vs, ws, gys = (host(x[sl]) for x in (r, k, v, w, gy))
+        us = host(u[h:h + 1])
+        check_bf16(y[sl], oracle.forward(rs, ks, vs, ws, us), f"config2 ({b},{h}) y")
+        og = oracle.backward(rs, ks, vs, ws, us, gys)
+        for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+            check_bf16(t[sl], og[n], f"config2 ({b},{h}) {n}")
+        assert max_norm_err(host(gu[b, 64 * h:64 * h + 64]), og["gu_b"][0]) <= 8e-3
+    # whole tensor: chunked (default) vs exact scan kernels in bf16
+    ys = ops.forward_ex(r, k, v, w, u, H, algo="scan")
+    agree_with_scan(y, ys, "y")
+    sgr, sgk, sgv, sgw, sgu, _ = ops.backward_ex(r, k, v, w, u, gy, H, algo="scan")
+    agree_with_scan(gr, sgr, "gr")
+    agree_with_scan(gk, sgk, "gk")
+    agree_with_scan(gv, sgv, "gv")
+    agree_with_scan(gw, sgw, "gw", exact=0.95, ulps=2.0)
+
+
+def test_config3_wkv6_bi_ragged_vs_oracle_slices(ops, oracle):
+    """BASELINE configs[2]: wkv6_bi, B=48 (16 x query/pos/neg), T=512, mask lengths U[64,512]."""
+    B, T, H = 48, 512, 32
+    r, k, v, w, u, gy = synth(B, T, H, seed=1)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    lens = torch.randint(64, 513, (B,), device="cuda", generator=g)
+    lens[0], lens[1] = 512, 64
+    mask = (torch.arange(T, device="cuda").view(1, T) < (lens.view(B, 1) - 1)).to(torch.int32).contiguous()
+    y = ops.bi_forward_ex(mask, r, k, v, w, u, H)
+    gr, gk, gv, gw, gu = ops.bi_backward_ex(mask, r, k, v, w, u, gy, H)
+    mh = mask.cpu().numpy()
+    for (b, h) in ((0, 0), (1, 31), (47, 13), (20, 7), (33, 22)):
+        sl = head_slice(b, h)
+        rs, ks, vs, ws, gys = (host(x[sl]) for x in (r, k, v, w, gy))
+        us = host(u[h:h + 1])
+        check_bf16(y[sl], oracle.bi_forward(mh[b:b + 1], rs, ks, vs, ws, us), f"bi ({b},{h}) y")
+        og = oracle.bi_backward(mh[b:b + 1], rs, ks, vs, ws, us, gys)
+        for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+            check_bf16(t[sl], og[n], f"bi ({b},{h}) {n}")
+        assert max_norm_err(host(gu[b, 64 * h:64 * h + 64]), og["gu_b"][0]) <= 8e-3
+        L = int(lens[b])
+        if L < T:                                                   # Q2: zero beyond the first masked token
+            assert float(y[b, L:].abs().max()) == 0.0 and float(gk[b, L:].abs().max()) == 0.0
+
+
+def test_config5_infctx_carry_vs_oracle_slice(ops, oracle):
+    """BASELINE configs[4]: B=4, T=16384 as 8 chunks of 2048 with the bf16 state carried between the calls
+    (src/model.py:1134-1192); each chunk's backward starts from its own entry state (truncated BPTT)."""
+    B, T, H, CH = 4, 16384, 32, 2048
+    r, k, v, w, u, gy = synth(B, T, H, seed=2)
+    states = [torch.zeros(B, H, 64, 64, device="cuda", dtype=bf) for _ in range(T // CH + 1)]
+    ys, grads = [], []
+    for c in range(T // CH):
+        sl = slice(CH * c, CH * (c + 1))
+        rc, kc, vc, wc, gc = (x[:, sl].contiguous() for x in (r, k, v, w, gy))
+        ys.append(ops.forward_ex(rc, kc, vc, wc, u, H, s0=states[c], s_out=states[c + 1]))
+        grads.append(ops.backward_ex(rc, kc, vc, wc, u, gc, H, s0=states[c], want_gs=True))
+    b, h = 3, 21
+    us = host(u[h:h + 1])
+    s_or = np.zeros((1, 1, 64, 64), np.float32)
+    for c in range(T // CH):
+        sl = (slice(b, b + 1), slice(CH * c, CH * (c + 1)), slice(64 * h, 64 * h + 64))
+        rs, ks, vs, ws, gys = (host(x[sl]) for x in (r, k, v, w, gy))
+        hs = head_slice(b, h)
+        yo, so = oracle.forward(rs, ks, vs, ws, us, s_or, return_state=True)
+        check_bf16(ys[c][hs], yo, f"infctx chunk {c} y")
+        og = oracle.backward(rs, ks, vs, ws, us, gys, s_or)
+        for n, t in zip(("gr", "gk", "gv", "gw"), grads[c][:4]):
+            check_bf16(t[hs], og[n], f"infctx chunk {c} {n}")
+        check_bf16(grads[c][5][b:b + 1, h:h + 1], og["gs_b"], f"infctx chunk {c} gs")
+        # the carry the kernel wrote (bf16) is the next chunk's entry state, for the oracle too
+        check_bf16(states[c + 1][b:b + 1, h:h + 1], so, f"infctx chunk {c} state")
+        s_or = host(states[c + 1][b:b + 1, h:h + 1])
+
+
+def test_extreme_decay_with_large_carried_state(ops, oracle):
+    """The chunked path clamps per-token log-decays at -9.  Decays far below that (w up to 3.5,
+    i.e. d = exp(-33)) next to a large carried state: the result must still meet the bf16 contract."""
+    B, T, H = 2, 200, 2
+    C = H * 64
+    g = torch.Generator().manual_seed(11)
+    f = lambda x: x.to(bf).float().numpy()
+    r, k, v = (f(torch.randn(B, T, C, generator=g) * 0.5) for _ in range(3))
+    w = f(-3.0 + 2.0 * torch.randn(B, T, C, generator=g))
+    w[:, 50:60, :32] = 3.5
+    w[:, 120, 32:] = 2.5
+    u = f(torch.randn(H, 64, generator=g) * 0.3)
+    gy = f(torch.randn(B, T, C, generator=g))
+    s0 = f(torch.randn(B, H, 64, 64, generator=g) * 30.0)
+    d = lambda x: torch.from_numpy(x).to("cuda", bf).contiguous()
+    y = ops.forward_ex(d(r), d(k), d(v), d(w), d(u), H, s0=d(s0))
+    check_bf16(y, oracle.forward(r, k, v, w, u, s0), "extreme y")
+    og = oracle.backward(r, k, v, w, u, gy, s0)
+    gr, gk, gv, gw, gu, gs = ops.backward_ex(d(r), d(k), d(v), d(w), d(u), d(gy), H, s0=d(s0), want_gs=True)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+        check_bf16(t, og[n], "extreme " + n)
