@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """WKV6 fwd+bwd micro-benchmark on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wkv6|infctx|bi] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wkv6|infctx|bi|dp_lora] [--no-cpu]
 
 One "step" = one forward + one backward of the WKV6 operator through the C ABI of librwkv6_amd.so on one
 batch of synthetic bf16 inputs that already live in HBM (BASELINE.json configs[1]: B=8, T=4096, C=2048,
@@ -80,18 +80,93 @@ def cpu_baseline(budget_s=20.0):
                       f"{el:.1f} s on {os.cpu_count()} host cpus"}
 
 
+def bench_dp_lora(args, rank, world, dev, dist):
+    """BASELINE configs[3]: LoRA bi-encoder step, DP over the ranks, gradient all-reduce through DDP (RCCL)."""
+    from rwkv_lm_ext_amd import train_dp
+    from rwkv_lm_ext_amd.dp import BucketBatchSampler, timed_steps
+    vocab, n_embd, dim_ffn, T, bs = 65536, 2048, 7168, 512, args.per_gpu_batch     # RWKV-x060-1B6 (SURVEY.md 8e)
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = train_dp.SequenceEmbedder(vocab, n_embd, args.layers, dim_ffn=dim_ffn, add_mlp=True, output_dim=1024,
+                                          grad_cp=True).to(torch.bfloat16)
+    with torch.no_grad():                           # random-init weights of the architecture (no checkpoints offline)
+        for n, p in model.named_parameters():
+            if p.dim() >= 2 and "emb" not in n:
+                p.normal_(0.0, 0.02)
+            if "time_decay" in n and p.dim() == 3:
+                p.copy_(torch.linspace(-6, -1, p.numel(), device=dev).view_as(p))
+            if "ln_x.weight" in n or (n.endswith(".weight") and ".ln" in n):
+                p.fill_(1.0)
+    train_dp.inject_lora(model, r=8, alpha=32)
+    for p in model.dense.parameters():
+        p.requires_grad_(True)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("lora_B"):
+                p.normal_(0.0, 0.01)
+    msg_bytes = train_dp.grad_allreduce_bytes(model)
+    net = train_dp.wrap_ddp(model, dev) if dist is not None else model
+    opt = torch.optim.AdamW(train_dp.trainable_parameters(model), lr=1e-5)
+    total = args.steps + args.warmup + 1
+    sampler = BucketBatchSampler([total * bs * world], [bs], rank, world)
+    # the rank's batches, dealt by the sampler, staged in pinned host memory ahead of the timed region
+    it = iter([{k: v.pin_memory() for k, v in b.items()} for b in train_dp.batches(sampler, T, vocab)])
+    model.train()
+
+    def step():
+        batch = {k: v.to(dev, non_blocking=True) for k, v in next(it).items()}
+        opt.zero_grad(set_to_none=True)
+        loss = train_dp.training_loss(net, batch["query"], batch["positive"], batch["negative"])
+        loss.backward()                             # DDP all-reduces the LoRA / dense gradients here
+        opt.step()
+
+    step()                                          # allocator / module-load warm-up, outside the W warm-up steps
+    torch.cuda.synchronize()
+    elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
+    if rank == 0:
+        tokens = 3 * bs * T                         # per GPU and step
+        print(json.dumps({
+            "metric": "LoRA bi-encoder training tokens/sec (RWKV-x060-1B6 shape, T=512, DP, RCCL grad all-reduce)",
+            "value": round(world * tokens * args.steps / elapsed, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": 1,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "peft_train_bi_encoder LoRA r=8 alpha=32 on ffn.key/value/receptance + dense head "
+                                   "(BASELINE configs[3])", "layers": args.layers, "n_embd": n_embd, "dim_ffn": dim_ffn,
+                       "seq_len": T, "per_gpu_batch": bs, "global_batch": bs * world,
+                       "sequences_per_gpu_step": 3 * bs, "grad_checkpointing": True,
+                       "parallelism": f"dp{world} (DDP, one bucketed all-reduce of the trainable gradients per step)",
+                       "allreduce_bytes_per_step": msg_bytes}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="wkv6", choices=["wkv6", "infctx", "bi"])
+    ap.add_argument("--workload", default="wkv6", choices=["wkv6", "infctx", "bi", "dp_lora"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--layers", type=int, default=24, help="dp_lora: number of RWKV blocks (1B6: 24)")
+    ap.add_argument("--per-gpu-batch", type=int, default=32, help="dp_lora: triples per GPU and step")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: spawn the ranks (nothing has touched the GPU yet) and relay
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the WKV6 operator has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -103,6 +178,8 @@ def main():
 
     from rwkv_lm_ext_amd import wkv6_op
 
+    if args.workload == "dp_lora":
+        return bench_dp_lora(args, rank, world, dev, dist)
     if args.workload == "wkv6":
         B, T, H = 8, 4096, 32
         name = "wkv6_fwd_bwd B=8 T=4096 C=2048 H=32 (BASELINE configs[1])"
@@ -168,7 +245,8 @@ def main():
     # Device pre-warm, outside both the W warm-up steps and the timed region: the GPU needs tens of milliseconds of
     # work to reach its sustained clocks (a 5-step warm-up is 4 ms), and the first launches pay module load / allocator
     # costs.  Nothing is cached by it: every step recomputes forward and backward from the same inputs.
-    for _ in range(64):
+    PREWARM = 64
+    for _ in range(PREWARM):
         fwd()
         bwd()
     torch.cuda.synchronize()
@@ -186,7 +264,7 @@ def main():
             "metric": "WKV6 fwd+bwd tokens/sec/GPU (B=8,T=4096,C=2048) + %HBM roofline",
             "value": round(world * tokens * args.steps / elapsed, 1),
             "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_iters": PREWARM,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",

@@ -116,7 +116,9 @@ size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H)
 }
 size_t wkv6bi_workspace_bytes(int B, int T, int C, int H)
 {
-    return align_up((size_t)B * sizeof(int)) + wkv6_backward_workspace_bytes(B, T, C, H);
+    // lens | backward workspace (forward: the fp32 y side buffer lives here) | 4 fp32 [B,T,C] gradient side buffers
+    return align_up((size_t)B * sizeof(int)) + wkv6_backward_workspace_bytes(B, T, C, H) +
+           4 * align_up((size_t)B * T * C * sizeof(float));
 }
 
 int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
@@ -226,6 +228,12 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
     a.gy = gy; a.gr = gr; a.gk = gk; a.gv = gv; a.gw = gw; a.gu = gu;
     a.lens = lens;
     a.zero_tail = 1;
+    if (!(flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN))) {
+        // chunked bf16 path: the first half goes to fp32 side buffers, the second adds it and rounds once
+        // (the reference accumulates `_gr[t] += F(gr)` in bf16, cuda/wkv6_bi_cuda.cu:199-200)
+        char* side = reinterpret_cast<char*>(aux) + wkv6_backward_workspace_bytes(B, T, C, H);
+        for (int i = 0; i < 4; ++i) a.g_f32[i] = reinterpret_cast<float*>(side + i * align_up((size_t)B * T * C * sizeof(float)));
+    }
     if (hipError_t e = run_bwd(a, flags, aux, st)) return (int)e;                    // adjoint of the forward scan
     a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0; a.gu = nullptr;   // adjoint of the reverse scan
     return to_rc(run_bwd(a, flags, aux, st));

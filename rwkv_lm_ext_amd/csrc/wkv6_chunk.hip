@@ -166,10 +166,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 // coefficient on the diagonal, split, and stored as the B fragment each consumer lane needs
                 // (lane: column a = x, k rows b = 4g+q).
                 const int x = lane & 15, g = lane >> 4;
-                // the stores above are uint2 / float typed, the fragment loads bf16x8 typed: without this fence type-based
-                // alias analysis lets the compiler hoist the loads above the stores
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                asm volatile("" ::: "memory");
+                // (the stores above are uint2 / float typed, the fragment loads bf16x8 typed: the library is built with
+                // -fno-strict-aliasing so that the loads stay below the stores; LDS operations of one wave execute in order)
                 f4v sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -225,15 +223,19 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
-            // every ds_read_b64_tr_b16 address of this iteration depends on this statement, which cannot move above the
-            // barrier: the transposed reads are guaranteed to be issued after the producers' writes are visible
-            asm volatile("" : "+v"(troff), "+v"(trow));
-            // Rolled on purpose (runtime trip count): a fully unrolled 4-block body was measured no faster and was
-            // miscompiled by hipcc 7.2 (wrong y in the first block of a group).
+
+            // Rolled (runtime trip count): a fully unrolled 4-block body is no faster.  -DWKV6_FWD_UNROLL builds the unrolled
+            // body for tools/check_unrolled_fwd.sh (the wrong y that build once produced was the mixed-shape
+            // MFMA accumulation hazard, not a reordered LDS read).
+#ifdef WKV6_FWD_UNROLL
+            constexpr int nb = NBLK;                              // blocks past the end are neutral (zero-filled operands)
+#pragma unroll
+#else
             const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
+#endif
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
-                if (a.ckpt && (blk * BLK) % a.ckpt_tok == 0) {   // state every ckpt_tok (64 or 32) tokens, for the backward kernel
+                if (a.ckpt && (blk * BLK) % a.ckpt_tok == 0 && grp * GRP + blk * BLK < a.T) {   // state every ckpt_tok tokens, for the backward kernel
                     float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) +
                                                 (grp * GRP + blk * BLK) / a.ckpt_tok) * (HEAD * HEAD);
 #pragma unroll

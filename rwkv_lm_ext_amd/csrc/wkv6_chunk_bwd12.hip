@@ -45,7 +45,8 @@ constexpr int BBLK_BYTES = BOFF_COEF + 128;
 constexpr int STG = 32, SBLK = STG / BLK;                             // tokens / blocks per stage
 constexpr int BUF_BYTES = SBLK * BBLK_BYTES;                           // one stage image; two of them
 
-#define WKV6_DPP_ACC(x, ctrl) asm("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
+// s_nop 1: a VALU write of a VGPR must be 2 wait states ahead of a DPP read of it, and nothing inside an asm string is padded
+#define WKV6_DPP_ACC(x, ctrl) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
 
 __device__ __forceinline__ float pick4(const f4v& v, int s)
 {
@@ -87,6 +88,22 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw) + base;
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
+    // gradient store: plain; or (wkv6_bi) first half into the fp32 side buffer, second half adds it and rounds once
+    auto emit = [&](int which, bf16_t* out, unsigned idx, float (&o)[4]) {
+        float* const side = a.g_f32[which];
+        if (side && !a.accumulate) {
+            io4<float>::store(side + base + idx, o);
+            return;
+        }
+        if (a.accumulate) {
+            float old[4];
+            if (side) io4<float>::load(side + base + idx, old);
+            else io4<bf16_t>::load(out + idx, old);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] += old[q];
+        }
+        io4<bf16_t>::store(out + idx, o);
+    };
 
     // ---- producer role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block pb
     const int c8i = lane & 7, tq = lane >> 3;
@@ -255,7 +272,6 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
                 }
             }
-            asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this iteration below the barrier
             const char* const buf = smem + (grp & 1) * BUF_BYTES;
 
             // ---- rebuild the entry state of block 1:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
@@ -359,13 +375,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
                         const unsigned idx = (unsigned)(t * a.C + ch);
-                        if (a.accumulate) {
-                            float o1[4];
-                            io4<bf16_t>::load(ogr + idx, o1);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) o_gr[q] += o1[q];
-                        }
-                        io4<bf16_t>::store(ogr + idx, o_gr);
+                        emit(0, ogr, idx, o_gr);
                     }
                 }
             }
@@ -433,15 +443,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     if (p < ntok) {
                         const int t = a.reverse ? ntok - 1 - p : p;
                         const unsigned idx = (unsigned)(t * a.C + ch);
-                        if (a.accumulate) {
-                            float o2[4], o3[4];
-                            io4<bf16_t>::load(ogk + idx, o2);
-                            io4<bf16_t>::load(ogw + idx, o3);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { o_gk[q] += o2[q]; o_gw[q] += o3[q]; }
-                        }
-                        io4<bf16_t>::store(ogk + idx, o_gk);
-                        io4<bf16_t>::store(ogw + idx, o_gw);
+                        emit(1, ogk, idx, o_gk);
+                        emit(3, ogw, idx, o_gw);
                     }
                 }
                 // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
@@ -466,7 +469,6 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         for (int t = 0; t < 4; ++t) GJ[t] = f4v{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
-            asm volatile("" : "+v"(troff), "+v"(trow));   // pins every transposed LDS read of this iteration below the barrier
             const char* const buf = smem + (grp & 1) * BUF_BYTES;
             // ---- pre-phase: everything that does not depend on G, stage-major over the 4 blocks so that many
             //      independent LDS reads / MFMAs are in flight (blocks past the end of the sequence are neutral)
@@ -552,13 +554,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                         const int t = a.reverse ? ntok - 1 - p : p;
                         const unsigned idx = (unsigned)(t * a.C + 16 * wv + 4 * g);
                         float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-                        if (a.accumulate) {
-                            float old[4];
-                            io4<bf16_t>::load(ogv + idx, old);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) o[q] += old[q];
-                        }
-                        io4<bf16_t>::store(ogv + idx, o);
+                        emit(2, ogv, idx, o);
                     }
                 }
                 // ---- G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)

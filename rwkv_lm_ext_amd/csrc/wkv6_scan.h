@@ -55,6 +55,9 @@ struct ScanArgs {
                                       // read as the addend (instead of y) when accumulate == 1  (wkv6_bi halves)
     const void* gy;                   // backward input
     void *gr, *gk, *gv, *gw;          // backward outputs, I/O type
+    float* g_f32[4];                  // optional fp32 side buffers [B,T,C] for gr,gk,gv,gw (chunked backward): written INSTEAD
+                                      // of the outputs when accumulate == 0, read as the addend when accumulate == 1, so the
+                                      // two halves of wkv6_bi are summed in fp32 and rounded once
     void* gu;                         // [B,C] per-batch partials, I/O type (null: skip)
     void* gs;                         // [B,H,N,N] per-batch dL/dS0, I/O type (null: skip)
     float* aux;                       // [B,T,C] fp32 scratch carrying a_t from sweep S to sweep G

@@ -168,11 +168,9 @@ def test_golden_bi(ops, io):
     assert np.all(yh[0, 31:] == 0) and np.all(yh[1, 18:] == 0) and np.all(yh[2, 1:] == 0)   # Q2: zero-filled
     gr, gk, gv, gw, gu = ops.bi_backward_ex(mask, r, k, v, w, u, gy, H)
     for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
-        if io == torch.float32:
-            check(t, g[n], io, "bi " + n)
-        else:   # the adjoints of the two scans are accumulated in the bf16 output (like the reference's
-            # `_gr[t] += F(gr)`, cuda/wkv6_bi_cuda.cu:199-200): each half is rounded once -> <= 8e-3 of max
-            assert max_norm_err(host(t), g[n]) <= 8e-3, n
+        # the adjoints of the two scans are summed in fp32 (side buffers) and rounded once: the suite's bf16 contract
+        # (the reference accumulates `_gr[t] += F(gr)` in bf16, cuda/wkv6_bi_cuda.cu:199-200)
+        check(t, g[n], io, "bi " + n)
         assert np.all(host(t)[1, 18:] == 0)
     assert max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"]) <= (F32_TOL if io == torch.float32 else 8e-3)
 

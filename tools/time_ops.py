@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Time the forward and the backward of the WKV6 operator separately (config 2 by default) with HIP events.
+Used by tools/ablate.sh with RWKV_AMD_LIB pointing at a variant library."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import synth                                           # noqa: E402
+from rwkv_lm_ext_amd import wkv6_op                               # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=8)
+ap.add_argument("--T", type=int, default=4096)
+ap.add_argument("--H", type=int, default=32)
+ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--only", default="both", choices=["both", "fwd", "bwd"])
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+B, T, H = args.B, args.T, args.H
+C = H * 64
+r, k, v, w, u, gy = synth(B, T, H, dev)
+y = torch.empty_like(r)
+ckpt = wkv6_op.new_checkpoint(B, T, C, H, dev)
+
+
+def run(fn, n):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+fwd = lambda: wkv6_op.forward_ex(r, k, v, w, u, H, y=y, ckpt=ckpt)
+bwd = lambda: wkv6_op.backward_ex(r, k, v, w, u, gy, H, ckpt=ckpt)
+for _ in range(30):
+    fwd()
+    if args.only != "fwd":
+        bwd()
+out = {}
+if args.only in ("both", "fwd"):
+    out["fwd_ms"] = round(run(fwd, args.iters), 4)
+if args.only in ("both", "bwd"):
+    out["bwd_ms"] = round(run(bwd, args.iters), 4)
+print(os.environ.get("ABL_NAME", "default"), out, flush=True)
+if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wave phase cycles of one forward launch
+    import ctypes
+    from rwkv_lm_ext_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(B * H * 16 * 4, dtype=torch.int64, device=dev)
+    lib.wkv6_set_debug_buffer.argtypes = [ctypes.c_void_p]
+    lib.wkv6_set_debug_buffer.restype = None
+    lib.wkv6_set_debug_buffer(buf.data_ptr())
+    fwd()
+    torch.cuda.synchronize()
+    d = buf.view(B * H, 16, 4).double().mean(0)         # average over workgroups: [wave][phase]
+    ng = (T + 63) // 64
+    print("per-group cycles per wave (avg over workgroups): consumers = [finish, body, barrier], producers = [load wait, prep+issue, barrier, prep only]")
+    for wv in range(16):
+        print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / ng):8.0f}" for k in range(4)))
+
