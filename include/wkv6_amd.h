@@ -120,6 +120,24 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
                        size_t workspace_bytes, unsigned flags, void* stream);
 size_t wkv6bi_workspace_bytes(int B, int T, int C, int H);
 
+/* ---- elementwise neighbours of the operator in the RWKV-6 time-mix block; bf16 only ----
+ * ddlerp (src/model.py:435-448): xx = shift(x) - x; out[s] = x + xx * (maa[s] + m[s]), s < NS.
+ *   x [B,T,C]; shifted0 [B,C] = token in front of each row (NULL: zero, nn.ZeroPad2d((0,0,1,-1))); m [NS,B,T,C] or NULL;
+ *   maa [NS,C]; out [NS,B,T,C].  Supported: (NS=1, m NULL or not), (NS=5, m given).
+ * backward: dx [B,T,C], dm [NS,B,T,C] (NULL iff m NULL), dmaa_part fp32 [nparts,NS,C] partial sums (caller adds them). */
+int wkv6_ddlerp_forward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
+                        void* out, void* stream);
+int wkv6_ddlerp_backward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
+                         const void* dout, void* dx, void* dm, float* dmaa_part, int nparts, void* stream);
+/* gn_gate (src/model.py:462-468): out = GroupNorm_H(y; gamma, beta, eps) * g on rows of C = 64 H channels (nn.GroupNorm(H, C)
+ * applied to [rows, C]); stats fp32 [rows,H,2] (mean, rstd) is written for the backward (may be NULL in inference).
+ * backward: dy, dg [rows,C]; dgamma_part, dbeta_part fp32 [nparts,C] partial sums. */
+int wkv6_gn_gate_forward(long rows, int C, int H, const void* y, const void* g, const void* gamma, const void* beta,
+                         float eps, void* out, float* stats, void* stream);
+int wkv6_gn_gate_backward(long rows, int C, int H, const void* y, const void* g, const void* gamma, const void* beta,
+                          const float* stats, const void* dout, void* dy, void* dg, float* dgamma_part, float* dbeta_part,
+                          int nparts, void* stream);
+
 /* Device self-test: the cross-lane primitives, then the chunked MFMA kernels against the exact scan kernels on a fixed
  * pseudo-random problem (forward and backward, all outputs within 2 bf16 ulps of the tensor scale, 4 for gw).
  * Returns 0 when it passes, WKV6_ESELFTEST (or the number of failed primitive checks) otherwise. */

@@ -11,6 +11,8 @@ from . import _build
 
 _VP = ctypes.c_void_p
 _I = ctypes.c_int
+_L = ctypes.c_long
+_F = ctypes.c_float
 _SZ = ctypes.c_size_t
 _U = ctypes.c_uint
 
@@ -33,6 +35,10 @@ SIGNATURES = {
     "wkv6_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
     "wkv6bi_forward_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ, _U, _VP]),
     "wkv6bi_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
+    "wkv6_ddlerp_forward": (_I, [_I] * 4 + [_VP] * 6),
+    "wkv6_ddlerp_backward": (_I, [_I] * 4 + [_VP] * 8 + [_I, _VP]),
+    "wkv6_gn_gate_forward": (_I, [_L, _I, _I] + [_VP] * 4 + [_F] + [_VP] * 3),
+    "wkv6_gn_gate_backward": (_I, [_L, _I, _I] + [_VP] * 10 + [_I, _VP]),
     "wkv6_selftest": (_I, [_VP]),
     "wkv6_amd_version": (ctypes.c_char_p, []),
 }

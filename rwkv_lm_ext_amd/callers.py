@@ -46,10 +46,12 @@ def _default_wkv(B, T, C, H, r, k, v, w, u):
 class Tmix_x060(nn.Module):
     """RWKV-6 time-mix around the WKV operator (src/model.py:376-477)."""
 
-    def __init__(self, n_embd, dim_att, head_size=64, head_size_divisor=8, wkv=None):
+    def __init__(self, n_embd, dim_att, head_size=64, head_size_divisor=8, wkv=None, fused=None):
+        """fused: None = the HIP elementwise kernels of mix_op whenever the input is a bf16 GPU tensor; True / False force."""
         super().__init__()
         self.n_head = dim_att // head_size
         self.wkv = wkv or _default_wkv
+        self.fused = fused
         d_mix = 64 if n_embd == 4096 else 32                              # TIME_MIX_EXTRA_DIM
         d_decay = 128 if n_embd == 4096 else 64                           # TIME_DECAY_EXTRA_DIM
         z = lambda *s: nn.Parameter(torch.zeros(*s))
@@ -68,33 +70,52 @@ class Tmix_x060(nn.Module):
         self.gate = nn.Linear(n_embd, dim_att, bias=False)
         self.ln_x = nn.GroupNorm(self.n_head, dim_att, eps=1e-5 * head_size_divisor ** 2)
 
+    def _maa5(self):
+        """[5,C]: the static lerp weights of the decay, key, value, receptance and gate inputs, in the order the
+        low-rank correction tensor is laid out (src/model.py:441-442: mw, mk, mv, mr, mg)."""
+        return torch.cat([self.time_maa_w, self.time_maa_k, self.time_maa_v, self.time_maa_r, self.time_maa_g], 0).view(5, -1)
+
+    def _use_fused(self, x):
+        if self.fused is None:
+            return x.is_cuda and x.dtype == torch.bfloat16
+        return self.fused
+
     def jit_func(self, x, shifted=None):
-        """token shift, data-dependent lerp (two low-rank GEMMs), r/k/v/g projections, decay LoRA (src/model.py:435-459).
+        """Inputs of the WKV operator from the block input (src/model.py:435-459): every projection reads its own
+        data-dependent blend of x_t and x_{t-1},  x + (x_{t-1} - x) * (maa_s + m_s),  where the five corrections m_s come
+        from one shared low-rank pair (tanh(blend_x @ W1) -> per-stream W2).  Then r, k, v = Linear(blend), g = silu(Linear),
+        w = time_decay + tanh(blend_w @ D1) @ D2.
         `shifted`: x delayed by one token; default zero-padded (nn.ZeroPad2d((0,0,1,-1))), the infctx path passes the
-        previous chunk's last token in front (src/model.py:740-741)."""
+        previous chunk's last token in front (src/model.py:740-741).
+        On bf16 GPU tensors the two blend stages are one HIP kernel each (mix_op.ddlerp)."""
         B, T, C = x.size()
-        xx = (F.pad(x, (0, 0, 1, -1)) if shifted is None else shifted) - x
-        xxx = x + xx * self.time_maa_x
-        xxx = torch.tanh(xxx @ self.time_maa_w1).view(B * T, 5, -1).transpose(0, 1)
-        xxx = torch.bmm(xxx, self.time_maa_w2).view(5, B, T, -1)
-        mw, mk, mv, mr, mg = xxx.unbind(dim=0)
-        xw = x + xx * (self.time_maa_w + mw)
-        xk = x + xx * (self.time_maa_k + mk)
-        xv = x + xx * (self.time_maa_v + mv)
-        xr = x + xx * (self.time_maa_r + mr)
-        xg = x + xx * (self.time_maa_g + mg)
-        r = self.receptance(xr)
-        k = self.key(xk)
-        v = self.value(xv)
-        g = F.silu(self.gate(xg))
-        w = self.time_decay + torch.tanh(xw @ self.time_decay_w1) @ self.time_decay_w2
-        return r, k, v, g, w
+        if self._use_fused(x):
+            from . import mix_op
+            first = None if shifted is None else shifted[:, 0].contiguous()
+            lead = mix_op.ddlerp(x, self.time_maa_x.view(1, C), None, first)[0]
+            low = torch.tanh(lead @ self.time_maa_w1).view(B * T, 5, -1).transpose(0, 1)
+            corr = torch.bmm(low, self.time_maa_w2).view(5, B, T, C)
+            xw, xk, xv, xr, xg = mix_op.ddlerp(x, self._maa5(), corr, first).unbind(0)
+        else:
+            prev = F.pad(x, (0, 0, 1, -1)) if shifted is None else shifted
+            delta = prev - x
+            lead = torch.addcmul(x, delta, self.time_maa_x)
+            low = torch.tanh(lead @ self.time_maa_w1).view(B * T, 5, -1).transpose(0, 1)
+            corr = torch.bmm(low, self.time_maa_w2).view(5, B, T, C)
+            xw, xk, xv, xr, xg = (x + delta * (self._maa5().view(5, 1, 1, C) + corr)).unbind(0)
+        decay = self.time_decay + torch.tanh(xw @ self.time_decay_w1) @ self.time_decay_w2
+        return self.receptance(xr), self.key(xk), self.value(xv), F.silu(self.gate(xg)), decay
 
     def jit_func_2(self, x, g):
-        """per-head GroupNorm, gate, output projection (src/model.py:462-468)."""
+        """per-head GroupNorm, gate, output projection (src/model.py:462-468); on bf16 GPU tensors the GroupNorm and the
+        gate multiply are one HIP kernel (mix_op.group_norm_gate)."""
         B, T, C = x.size()
-        x = self.ln_x(x.view(B * T, C)).view(B, T, C)
-        return self.output(x * g)
+        if self._use_fused(x):
+            from . import mix_op
+            gated = mix_op.group_norm_gate(x.reshape(B * T, C), g.reshape(B * T, C), self.ln_x.weight, self.ln_x.bias,
+                                           self.n_head, self.ln_x.eps).view(B, T, C)
+            return self.output(gated)
+        return self.output(self.ln_x(x.view(B * T, C)).view(B, T, C) * g)
 
     def _run(self, r, k, v, w):
         B, T, C = r.shape

@@ -1,0 +1,97 @@
+"""Fused elementwise neighbours of the WKV6 operator in the RWKV-6 time-mix block, served by librwkv6_amd.so
+(csrc/wkv6_mix.hip): the token-shift / data-dependent-lerp chain in front of the projections (src/model.py:435-448,
+SURVEY.md row n4) and the per-head GroupNorm + gate behind the operator (src/model.py:462-468, row n1).
+
+bf16 GPU tensors only; like the operator itself there is no CPU path.  Each op is a torch.autograd.Function whose
+forward and backward are one HIP kernel each; parameter gradients come back as fp32 partial rows summed here."""
+import torch
+
+from . import _lib
+from .wkv6_op import _check_tensors, _ptr, _stream_ptr   # noqa: F401  (same validation / stream conventions)
+
+_NPARTS = 1024
+
+
+def _require(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16):
+        raise RuntimeError(f"{name} must be a bf16 GPU tensor (the fused time-mix ops have no CPU path)")
+    return t.contiguous()
+
+
+class _DDLerp(torch.autograd.Function):
+    """out[s] = x + (shift(x) - x) * (maa[s] + m[s]);  x [B,T,C], maa [NS,C], m [NS,B,T,C] or None -> out [NS,B,T,C]."""
+
+    @staticmethod
+    def forward(ctx, x, maa, m, shifted0):
+        x, maa = _require(x, "x"), _require(maa, "maa")
+        m = None if m is None else _require(m, "m")
+        shifted0 = None if shifted0 is None else _require(shifted0, "shifted0")
+        B, T, C = x.shape
+        NS = maa.shape[0]
+        out = torch.empty((NS, B, T, C), device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().wkv6_ddlerp_forward(B, T, C, NS, _ptr(x), _ptr(shifted0), _ptr(m), _ptr(maa), _ptr(out),
+                                                 _stream_ptr())
+        _lib.check(rc, "ddlerp forward")
+        ctx.save_for_backward(x, maa, m, shifted0)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, maa, m, shifted0 = ctx.saved_tensors
+        dout = _require(dout, "dout")
+        B, T, C = x.shape
+        NS = maa.shape[0]
+        nparts = min(_NPARTS, B * T)
+        dx = torch.empty_like(x)
+        dm = None if m is None else torch.empty_like(m)
+        part = torch.empty((nparts, NS, C), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().wkv6_ddlerp_backward(B, T, C, NS, _ptr(x), _ptr(shifted0), _ptr(m), _ptr(maa), _ptr(dout),
+                                                  _ptr(dx), _ptr(dm), _ptr(part), nparts, _stream_ptr())
+        _lib.check(rc, "ddlerp backward")
+        return dx, part.sum(0).to(maa.dtype), dm, None      # the token in front of the row (infctx carry) gets no gradient
+
+
+def ddlerp(x, maa, m=None, shifted0=None):
+    """maa: [NS,C] (or anything reshapeable to it, e.g. five [1,1,C] parameters stacked)."""
+    return _DDLerp.apply(x, maa.reshape(-1, x.shape[-1]), m, shifted0)
+
+
+class _GroupNormGate(torch.autograd.Function):
+    """out = GroupNorm_H(y) * g  on [rows, C] with C = 64 H."""
+
+    @staticmethod
+    def forward(ctx, y, g, gamma, beta, H, eps):
+        y, g, gamma, beta = _require(y, "y"), _require(g, "g"), _require(gamma, "gamma"), _require(beta, "beta")
+        C = y.shape[-1]
+        rows = y.numel() // C
+        out = torch.empty_like(y)
+        stats = torch.empty((rows, H, 2), device=y.device, dtype=torch.float32)
+        with torch.cuda.device(y.device):
+            rc = _lib.load().wkv6_gn_gate_forward(rows, C, H, _ptr(y), _ptr(g), _ptr(gamma), _ptr(beta), float(eps),
+                                                  _ptr(out), _ptr(stats), _stream_ptr())
+        _lib.check(rc, "gn_gate forward")
+        ctx.save_for_backward(y, g, gamma, beta, stats)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, g, gamma, beta, stats = ctx.saved_tensors
+        dout = _require(dout, "dout")
+        C = y.shape[-1]
+        rows = y.numel() // C
+        nparts = min(_NPARTS, rows)
+        dy, dg = torch.empty_like(y), torch.empty_like(g)
+        pg = torch.empty((nparts, C), device=y.device, dtype=torch.float32)
+        pb = torch.empty((nparts, C), device=y.device, dtype=torch.float32)
+        with torch.cuda.device(y.device):
+            rc = _lib.load().wkv6_gn_gate_backward(rows, C, ctx.H, _ptr(y), _ptr(g), _ptr(gamma), _ptr(beta), _ptr(stats),
+                                                   _ptr(dout), _ptr(dy), _ptr(dg), _ptr(pg), _ptr(pb), nparts, _stream_ptr())
+        _lib.check(rc, "gn_gate backward")
+        return dy, dg, pg.sum(0).to(gamma.dtype), pb.sum(0).to(beta.dtype), None, None
+
+
+def group_norm_gate(y, g, gamma, beta, n_head, eps):
+    return _GroupNormGate.apply(y, g, gamma, beta, n_head, eps)

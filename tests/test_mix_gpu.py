@@ -1,0 +1,128 @@
+"""Fused elementwise neighbours of the operator (csrc/wkv6_mix.hip) on the GPU against the same
+math in plain PyTorch fp32 on the same bf16 inputs, and -- through the time-mix module -- against the vectors captured from
+the reference's module (tests/golden/callers.npz).
+
+Tolerances: outputs are bf16: |out - RNE_bf16(ref)| <= 1 bf16 ulp of max(|ref|, 1e-2 max|ref|) and rel-rms <= 2e-3 (one
+rounding of an fp32 result); parameter gradients (fp32 partial sums over rows, rounded once) max-normalised <= 1e-2."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import bf16_report, load_golden, max_norm_err
+
+pytestmark = pytest.mark.gpu
+bf = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def mix():
+    assert torch.cuda.is_available()
+    from rwkv_lm_ext_amd import mix_op
+    return mix_op
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(bf).cuda()
+
+
+def close(out, ref, what, ulps=1.01, rms=2e-3):
+    r, off, u = bf16_report(out.detach().float().cpu().numpy(), ref.detach().float().cpu().numpy())
+    assert r <= rms and u <= ulps, f"{what}: rel-rms {r:.2e}, {u:.2f} ulp, {off * 100:.1f}% not correctly rounded"
+
+
+def ddlerp_ref(x, maa, m, first):
+    x, maa = x.float(), maa.float()
+    prev = F.pad(x, (0, 0, 1, -1))
+    if first is not None:
+        prev[:, 0] = first.float()
+    delta = prev - x
+    mm = 0 if m is None else m.float()
+    return x + delta * (maa.view(-1, 1, 1, x.shape[-1]) + mm)
+
+
+@pytest.mark.parametrize("ns,has_m,carry", [(1, False, False), (5, True, False), (5, True, True), (1, True, True)])
+def test_ddlerp_forward_backward(mix, ns, has_m, carry):
+    B, T, C = 3, 37, 256
+    x = rnd(B, T, C, seed=1).requires_grad_(True)
+    maa = rnd(ns, C, scale=0.5, seed=2).requires_grad_(True)
+    m = rnd(ns, B, T, C, scale=0.3, seed=3).requires_grad_(True) if has_m else None
+    first = rnd(B, C, seed=4) if carry else None
+    out = mix.ddlerp(x, maa, m, first)
+    assert out.shape == (ns, B, T, C) and out.dtype == bf
+    xr, mr_, mm_ = x.detach().clone().requires_grad_(True), maa.detach().clone().requires_grad_(True), \
+        (m.detach().clone().requires_grad_(True) if has_m else None)
+    ref = ddlerp_ref(xr, mr_, mm_, first)
+    close(out, ref, "ddlerp out")
+    dout = rnd(ns, B, T, C, seed=5)
+    out.backward(dout)
+    ref.backward(dout.float())
+    close(x.grad, xr.grad, "ddlerp dx", ulps=1.5)
+    if has_m:
+        close(m.grad, mm_.grad, "ddlerp dm")
+    assert max_norm_err(maa.grad.float().cpu().numpy(), mr_.grad.cpu().numpy()) <= 1e-2
+
+
+def test_group_norm_gate_forward_backward(mix):
+    rows, H = 301, 4
+    C = 64 * H
+    eps = 1e-5 * 64
+    y = rnd(rows, C, scale=2.0, seed=6).requires_grad_(True)
+    g = rnd(rows, C, seed=7).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=torch.Generator().manual_seed(8))).to(bf).cuda().requires_grad_(True)
+    beta = rnd(C, scale=0.1, seed=9).requires_grad_(True)
+    out = mix.group_norm_gate(y, g, gamma, beta, H, eps)
+    leaves = [t.detach().float().clone().requires_grad_(True) for t in (y, g, gamma, beta)]
+    ref = F.group_norm(leaves[0], H, leaves[2], leaves[3], eps) * leaves[1]
+    close(out, ref, "gn_gate out")
+    dout = rnd(rows, C, seed=10)
+    out.backward(dout)
+    ref.backward(dout.float())
+    close(y.grad, leaves[0].grad, "gn_gate dy", ulps=1.5)
+    close(g.grad, leaves[1].grad, "gn_gate dg")
+    assert max_norm_err(gamma.grad.float().cpu().numpy(), leaves[2].grad.cpu().numpy()) <= 1e-2
+    assert max_norm_err(beta.grad.float().cpu().numpy(), leaves[3].grad.cpu().numpy()) <= 1e-2
+
+
+def test_full_width_rows(mix):
+    """C = 2048 (512 threads per row), many rows: the launch shape of the 1B6 model."""
+    B, T, C, H = 2, 640, 2048, 32
+    x, maa, m = rnd(B, T, C, seed=11), rnd(5, C, scale=0.5, seed=12), rnd(5, B, T, C, scale=0.3, seed=13)
+    close(mix.ddlerp(x, maa, m), ddlerp_ref(x, maa, m, None), "ddlerp C=2048")
+    y, g = rnd(B * T, C, seed=14), rnd(B * T, C, seed=15)
+    gamma, beta = rnd(C, seed=16), rnd(C, seed=17)
+    ref = F.group_norm(y.float(), H, gamma.float(), beta.float(), 6.4e-4) * g.float()
+    close(mix.group_norm_gate(y, g, gamma, beta, H, 6.4e-4), ref, "gn_gate C=2048")
+
+
+def test_time_mix_module_fused_matches_reference_vectors_and_unfused():
+    """Tmix_x060 with the fused stages against the reference module's captured outputs, and gradients of the fused module
+    against the unfused (plain PyTorch) module on the same bf16 weights."""
+    from oracle import caller_weights as cw
+    from rwkv_lm_ext_amd import callers
+    gold = {k: torch.from_numpy(v) for k, v in load_golden("callers").items()}
+
+    def make(fused):
+        tm = callers.Tmix_x060(cw.N_EMBD, cw.DIM_ATT, fused=fused)
+        tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
+        return tm.cuda().to(bf)
+
+    x = gold["x"].cuda().to(bf)
+    outs, grads = [], []
+    for fused in (True, False):
+        tm = make(fused)
+        xi = x.clone().requires_grad_(True)
+        r, k, v, g, w = tm.jit_func(xi)
+        if fused:
+            for got, name in ((r, "r"), (k, "k"), (v, "v"), (g, "g"), (w, "w")):
+                assert max_norm_err(got.detach().float().cpu().numpy(), gold[name].numpy()) <= 3e-2, name
+        out = tm(xi)
+        assert max_norm_err(out.detach().float().cpu().numpy(), gold["out"].numpy()) <= 3e-2
+        out.float().pow(2).sum().backward()
+        outs.append(out.detach().float())
+        grads.append({n: p.grad.float() for n, p in tm.named_parameters()} | {"x": xi.grad.float()})
+    assert max_norm_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) <= 2e-2
+    for n in grads[0]:
+        e = max_norm_err(grads[0][n].cpu().numpy(), grads[1][n].cpu().numpy())
+        assert e <= 6e-2, (n, e)          # two bf16 pipelines of ~10 ops each against one another
