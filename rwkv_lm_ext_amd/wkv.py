@@ -180,8 +180,10 @@ class RWKV_6(torch.autograd.Function):
                 wkv6_op.rwkv6.forward_bf16(B, T, C, H, state, r, k, v, eew, u, y)
             elif r.dtype == torch.float32:
                 wkv6_op.rwkv6.forward_fp32(B, T, C, H, state, r, k, v, eew, u, y)
-            else:
+            elif r.dtype == torch.float16:
                 wkv6_op.rwkv6.forward_fp16(B, T, C, H, state, r, k, v, eew, u, y)
+            else:
+                raise RuntimeError(f"unsupported dtype {r.dtype}")
             return y, state
 
 

@@ -182,8 +182,17 @@ class _Rwkv6:
         _Rwkv6._call(B, T, C, H, state, r, k, v, w, u, y, torch.float32)
 
     @staticmethod
-    def forward_fp16(*args):
-        raise RuntimeError("rwkv6.forward_fp16 is not provided by the MI355X build (bf16 and fp32 are)")
+    def forward_fp16(B, T, C, H, state, r, k, v, w, u, y):
+        """cuda/rwkv6_op.cpp:16-19.  The reference's fp16 kernel widens every input to fp32, computes in fp32 and rounds y
+        to fp16 (cuda/rwkv6.cu:8-71); fp16 -> fp32 is exact, so running the fp32 kernel on widened copies and rounding its
+        output once gives the same values."""
+        for n, t in (("r", r), ("k", k), ("v", v), ("u", u), ("y", y)):
+            if not (isinstance(t, torch.Tensor) and t.dtype == torch.float16 and t.is_cuda):
+                raise RuntimeError(f"{n} must be a float16 GPU tensor")
+        y32 = torch.empty((B, T, C), device=y.device, dtype=torch.float32)
+        _Rwkv6._call(B, T, C, H, state, r.float().contiguous(), k.float().contiguous(), v.float().contiguous(), w,
+                     u.float().contiguous(), y32, torch.float32)
+        y.copy_(y32)
 
 
 rwkv6 = _Rwkv6
@@ -327,6 +336,12 @@ def _register():
                        f"Tensor(c!) gv, Tensor(d!) gw, Tensor(e!) gu, Tensor(f!) gs) -> ()", _Wkv6Infctx),
     }
     libs = []
+    rw = torch.library.Library("rwkv6", "DEF")          # TORCH_LIBRARY(rwkv6, m), cuda/rwkv6_op.cpp:30-34
+    for name in ("forward_bf16", "forward_fp16", "forward_fp32"):
+        rw.define(name + "(int B, int T, int C, int H, Tensor(s!) state, Tensor r, Tensor k, Tensor v, Tensor w, Tensor u, "
+                         "Tensor(a!) y) -> ()")
+        rw.impl(name, getattr(_Rwkv6, name), "CUDA")
+    libs.append(rw)
     for ns, (fwd_schema, bwd_schema, impl) in defs.items():
         lib = torch.library.Library(ns, "DEF")
         lib.define("forward" + fwd_schema)

@@ -51,17 +51,18 @@ def test_ddlerp_forward_backward(mix, ns, has_m, carry):
     first = rnd(B, C, seed=4) if carry else None
     out = mix.ddlerp(x, maa, m, first)
     assert out.shape == (ns, B, T, C) and out.dtype == bf
-    xr, mr_, mm_ = x.detach().clone().requires_grad_(True), maa.detach().clone().requires_grad_(True), \
-        (m.detach().clone().requires_grad_(True) if has_m else None)
-    ref = ddlerp_ref(xr, mr_, mm_, first)
+    # reference: the same math in fp32 on the CPU
+    cpu = lambda t: None if t is None else t.detach().float().cpu().clone()
+    xr, mr_, mm_ = cpu(x).requires_grad_(True), cpu(maa).requires_grad_(True), (cpu(m).requires_grad_(True) if has_m else None)
+    ref = ddlerp_ref(xr, mr_, mm_, cpu(first))
     close(out, ref, "ddlerp out")
     dout = rnd(ns, B, T, C, seed=5)
     out.backward(dout)
-    ref.backward(dout.float())
+    ref.backward(cpu(dout))
     close(x.grad, xr.grad, "ddlerp dx", ulps=1.5)
     if has_m:
         close(m.grad, mm_.grad, "ddlerp dm")
-    assert max_norm_err(maa.grad.float().cpu().numpy(), mr_.grad.cpu().numpy()) <= 1e-2
+    assert max_norm_err(maa.grad.float().cpu().numpy(), mr_.grad.numpy()) <= 1e-2
 
 
 def test_group_norm_gate_forward_backward(mix):
@@ -73,26 +74,29 @@ def test_group_norm_gate_forward_backward(mix):
     gamma = (1 + 0.2 * torch.randn(C, generator=torch.Generator().manual_seed(8))).to(bf).cuda().requires_grad_(True)
     beta = rnd(C, scale=0.1, seed=9).requires_grad_(True)
     out = mix.group_norm_gate(y, g, gamma, beta, H, eps)
-    leaves = [t.detach().float().clone().requires_grad_(True) for t in (y, g, gamma, beta)]
+    # reference in fp32 on the CPU (F.group_norm's weight gradient on the GPU disagrees with the definition for [N,C] inputs)
+    leaves = [t.detach().float().cpu().clone().requires_grad_(True) for t in (y, g, gamma, beta)]
     ref = F.group_norm(leaves[0], H, leaves[2], leaves[3], eps) * leaves[1]
     close(out, ref, "gn_gate out")
     dout = rnd(rows, C, seed=10)
     out.backward(dout)
-    ref.backward(dout.float())
+    ref.backward(dout.float().cpu())
+    xh = F.group_norm(leaves[0].detach(), H, None, None, eps)
+    assert max_norm_err(leaves[2].grad.numpy(), (dout.float().cpu() * leaves[1].detach() * xh).sum(0).numpy()) <= 1e-5
     close(y.grad, leaves[0].grad, "gn_gate dy", ulps=1.5)
     close(g.grad, leaves[1].grad, "gn_gate dg")
-    assert max_norm_err(gamma.grad.float().cpu().numpy(), leaves[2].grad.cpu().numpy()) <= 1e-2
-    assert max_norm_err(beta.grad.float().cpu().numpy(), leaves[3].grad.cpu().numpy()) <= 1e-2
+    assert max_norm_err(gamma.grad.float().cpu().numpy(), leaves[2].grad.numpy()) <= 1e-2
+    assert max_norm_err(beta.grad.float().cpu().numpy(), leaves[3].grad.numpy()) <= 1e-2
 
 
 def test_full_width_rows(mix):
     """C = 2048 (512 threads per row), many rows: the launch shape of the 1B6 model."""
     B, T, C, H = 2, 640, 2048, 32
     x, maa, m = rnd(B, T, C, seed=11), rnd(5, C, scale=0.5, seed=12), rnd(5, B, T, C, scale=0.3, seed=13)
-    close(mix.ddlerp(x, maa, m), ddlerp_ref(x, maa, m, None), "ddlerp C=2048")
+    close(mix.ddlerp(x, maa, m), ddlerp_ref(x.cpu(), maa.cpu(), m.cpu(), None), "ddlerp C=2048")
     y, g = rnd(B * T, C, seed=14), rnd(B * T, C, seed=15)
     gamma, beta = rnd(C, seed=16), rnd(C, seed=17)
-    ref = F.group_norm(y.float(), H, gamma.float(), beta.float(), 6.4e-4) * g.float()
+    ref = F.group_norm(y.float().cpu(), H, gamma.float().cpu(), beta.float().cpu(), 6.4e-4) * g.float().cpu()
     close(mix.group_norm_gate(y, g, gamma, beta, H, 6.4e-4), ref, "gn_gate C=2048")
 
 
@@ -108,21 +112,25 @@ def test_time_mix_module_fused_matches_reference_vectors_and_unfused():
         tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
         return tm.cuda().to(bf)
 
-    x = gold["x"].cuda().to(bf)
+    x = gold["x"]
     outs, grads = [], []
-    for fused in (True, False):
-        tm = make(fused)
-        xi = x.clone().requires_grad_(True)
-        r, k, v, g, w = tm.jit_func(xi)
+    for fused in (True, False):        # fused: bf16 on the GPU through the HIP kernels; unfused: fp32 on the CPU, oracle WKV
         if fused:
-            for got, name in ((r, "r"), (k, "k"), (v, "v"), (g, "g"), (w, "w")):
-                assert max_norm_err(got.detach().float().cpu().numpy(), gold[name].numpy()) <= 3e-2, name
+            tm = make(True)
+            xi = x.cuda().to(bf).requires_grad_(True)
+        else:
+            from oracle.wkv6_torch_naive import wkv6_naive
+            tm = callers.Tmix_x060(cw.N_EMBD, cw.DIM_ATT, fused=False, wkv=lambda B, T, C, H, r, k, v, w, u: wkv6_naive(r, k, v, w, u))
+            tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
+            xi = x.clone().requires_grad_(True)
+        r, k, v, g, w = tm.jit_func(xi)
+        for got, name in ((r, "r"), (k, "k"), (v, "v"), (g, "g"), (w, "w")):
+            assert max_norm_err(got.detach().float().cpu().numpy(), gold[name].numpy()) <= (3e-2 if fused else 1e-4), name
         out = tm(xi)
-        assert max_norm_err(out.detach().float().cpu().numpy(), gold["out"].numpy()) <= 3e-2
+        assert max_norm_err(out.detach().float().cpu().numpy(), gold["out"].numpy()) <= (3e-2 if fused else 1e-4)
         out.float().pow(2).sum().backward()
-        outs.append(out.detach().float())
-        grads.append({n: p.grad.float() for n, p in tm.named_parameters()} | {"x": xi.grad.float()})
-    assert max_norm_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) <= 2e-2
+        outs.append(out.detach().float().cpu())
+        grads.append({n: p.grad.float().cpu() for n, p in tm.named_parameters()} | {"x": xi.grad.float().cpu()})
     for n in grads[0]:
-        e = max_norm_err(grads[0][n].cpu().numpy(), grads[1][n].cpu().numpy())
-        assert e <= 6e-2, (n, e)          # two bf16 pipelines of ~10 ops each against one another
+        e = max_norm_err(grads[0][n].numpy(), grads[1][n].numpy())
+        assert e <= 8e-2, (n, e)          # a bf16 pipeline of ~12 ops (GEMMs, WKV, fused stages) against fp32
