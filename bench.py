@@ -11,7 +11,7 @@ reported value is the whole-job rate: N * tokens / max-over-ranks time.  Rank 0 
 
 Algorithmic bytes: forward reads r,k,v,w and writes y = 10 B per token-channel, backward
 reads r,k,v,w,gy and writes gr,gk,gv,gw = 18 B; 28 B per token-channel for the step.  The forward also writes, and
-the backward reads, one fp32 64x64 state checkpoint per 64 tokens (4 B per token-channel each way) -- real traffic
+the backward reads, one fp32 64x64 state checkpoint per 32 tokens (8 B per token-channel each way) -- real traffic
 (reported in roofline.traffic) that is NOT counted in the algorithmic figure.
 """
 import argparse
@@ -206,14 +206,15 @@ def main():
         chunks = [slice(2048 * c, 2048 * (c + 1)) for c in range(8)]
         parts = [[x[:, sl].contiguous() for x in (r, k, v, w, gy)] for sl in chunks]
         states = [torch.zeros(B, H, 64, 64, device=dev, dtype=torch.bfloat16) for _ in range(9)]
+        ckpts = [wkv6_op.new_checkpoint(B, 2048, C, H, dev) for _ in range(8)]   # as WKV_6STATE_INFCTX keeps them
 
         def fwd():
             for c, (rc, kc, vc, wc, _) in enumerate(parts):
-                wkv6_op.forward_ex(rc, kc, vc, wc, u, H, s0=states[c], s_out=states[c + 1])
+                wkv6_op.forward_ex(rc, kc, vc, wc, u, H, s0=states[c], s_out=states[c + 1], ckpt=ckpts[c])
 
         def bwd():      # truncated BPTT as the reference trains it: each chunk's backward from its entry state
             for c, (rc, kc, vc, wc, gc) in enumerate(parts):
-                wkv6_op.backward_ex(rc, kc, vc, wc, u, gc, H, s0=states[c], want_gs=True)
+                wkv6_op.backward_ex(rc, kc, vc, wc, u, gc, H, s0=states[c], want_gs=True, ckpt=ckpts[c])
     else:
         g = torch.Generator(device=dev).manual_seed(1)
         lens = torch.randint(64, 513, (B,), device=dev, generator=g)

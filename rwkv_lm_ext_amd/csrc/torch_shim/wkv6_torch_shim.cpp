@@ -10,8 +10,9 @@
 // -DWKV6_SHIM_PREFIX=foo registers the libraries as foo_wkv6, foo_wkv6bi, ... (lets a process that has already imported
 // rwkv_lm_ext_amd.wkv6_op, which defines torch.ops.wkv6*, load the shim as well).
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// ROCm builds of PyTorch keep the "cuda" device type for HIP tensors; the matching guard and stream live in these headers
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "wkv6_amd.h"
 
@@ -19,7 +20,8 @@ namespace {
 
 using torch::Tensor;
 
-void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
 
 void need(const Tensor& t, const char* name, at::ScalarType dt, const Tensor& like)
 {
@@ -43,7 +45,7 @@ void wkv6_forward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tensor&
 {
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", BF, r); need_btc(y, "y", B, T, C, BF, r);
-    const c10::hip::HIPGuard guard(r.device());
+    const DeviceGuard guard(r.device());
     ok(wkv6_cuda_forward(B, T, C, H, r.data_ptr(), k.data_ptr(), v.data_ptr(), w.data_ptr<float>(), u.data_ptr(), y.data_ptr(),
                          stream_of(r)), "wkv6 forward");
 }
@@ -55,7 +57,7 @@ void wkv6_backward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tensor
     need_btc(gr, "gr", B, T, C, BF, r); need_btc(gk, "gk", B, T, C, BF, r); need_btc(gv, "gv", B, T, C, BF, r);
     need_btc(gw, "gw", B, T, C, BF, r); need(gu, "gu", BF, r);
     TORCH_CHECK(gu.numel() == B * C, "gu must be [B,C]");
-    const c10::hip::HIPGuard guard(r.device());
+    const DeviceGuard guard(r.device());
     ok(wkv6_cuda_backward(B, T, C, H, r.data_ptr(), k.data_ptr(), v.data_ptr(), w.data_ptr<float>(), u.data_ptr(), gy.data_ptr(),
                           gr.data_ptr(), gk.data_ptr(), gv.data_ptr(), gw.data_ptr(), gu.data_ptr(), stream_of(r)), "wkv6 backward");
 }
@@ -68,7 +70,7 @@ void wkv6bi_forward(int64_t B, int64_t T, int64_t C, int64_t H, const Tensor& ma
     TORCH_CHECK(mask.numel() == B * T, "mask must be [B,T]");
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", BF, r); need_btc(y, "y", B, T, C, BF, r);
-    const c10::hip::HIPGuard guard(r.device());
+    const DeviceGuard guard(r.device());
     ok(wkv6bi_cuda_forward(B, T, C, H, mask.data_ptr<int>(), r.data_ptr(), k.data_ptr(), v.data_ptr(), w.data_ptr<float>(),
                            u.data_ptr(), y.data_ptr(), stream_of(r)), "wkv6_bi forward");
 }
@@ -80,7 +82,7 @@ void wkv6bi_backward(int64_t B, int64_t T, int64_t C, int64_t H, const Tensor& m
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", BF, r); need_btc(gy, "gy", B, T, C, BF, r);
     need_btc(gr, "gr", B, T, C, BF, r); need_btc(gk, "gk", B, T, C, BF, r); need_btc(gv, "gv", B, T, C, BF, r);
     need_btc(gw, "gw", B, T, C, BF, r); need(gu, "gu", BF, r);
-    const c10::hip::HIPGuard guard(r.device());
+    const DeviceGuard guard(r.device());
     ok(wkv6bi_cuda_backward(B, T, C, H, mask.data_ptr<int>(), r.data_ptr(), k.data_ptr(), v.data_ptr(), w.data_ptr<float>(),
                             u.data_ptr(), gy.data_ptr(), gr.data_ptr(), gk.data_ptr(), gv.data_ptr(), gw.data_ptr(), gu.data_ptr(),
                             stream_of(r)), "wkv6_bi backward");
@@ -94,7 +96,7 @@ void state_forward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tensor
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, BF, r); need(u, "u", BF, r); need(s, "s", BF, r); need_btc(y, "y", B, T, C, BF, r);
     TORCH_CHECK(s.numel() == (INFCTX ? B : 1) * H * 64 * 64, "s must be ", INFCTX ? "[B,H,N,N]" : "[H,N,N]");
-    const c10::hip::HIPGuard guard(r.device());
+    const DeviceGuard guard(r.device());
     if (INFCTX)
         ok(wkv6infctx_cuda_forward(B, T, C, H, r.data_ptr(), k.data_ptr(), v.data_ptr(), w.data_ptr(), u.data_ptr(), s.data_ptr(),
                                    y.data_ptr(), stream_of(r)), "wkv6infctx forward");
@@ -111,7 +113,7 @@ void state_backward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tenso
     need_btc(gr, "gr", B, T, C, BF, r); need_btc(gk, "gk", B, T, C, BF, r); need_btc(gv, "gv", B, T, C, BF, r);
     need_btc(gw, "gw", B, T, C, BF, r); need(gu, "gu", BF, r); need(gs, "gs", BF, r);
     TORCH_CHECK(gs.numel() == B * H * 64 * 64, "gs must be [B,H,N,N]");
-    const c10::hip::HIPGuard guard(r.device());
+    const DeviceGuard guard(r.device());
     auto fn = INFCTX ? wkv6infctx_cuda_backward : wkv6state_cuda_backward;
     ok(fn(B, T, C, H, r.data_ptr(), k.data_ptr(), v.data_ptr(), w.data_ptr(), u.data_ptr(), s.data_ptr(), gy.data_ptr(),
           gr.data_ptr(), gk.data_ptr(), gv.data_ptr(), gw.data_ptr(), gu.data_ptr(), gs.data_ptr(), stream_of(r)),
@@ -126,7 +128,7 @@ void rwkv6_forward_bf16(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& stat
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", BF, r); need_btc(y, "y", B, T, C, BF, r);
     TORCH_CHECK(state.numel() == B * H * 64 * 64, "state must be [B,H,N,N] ([H,N,N] for B = 1)");
-    const c10::hip::HIPGuard guard(r.device());
+    const DeviceGuard guard(r.device());
     ok(rwkv6_cuda_forward_bf16(B, T, C, H, state.data_ptr<float>(), r.data_ptr(), k.data_ptr(), v.data_ptr(), w.data_ptr<float>(),
                                u.data_ptr(), y.data_ptr(), stream_of(r)), "rwkv6 forward_bf16");
 }
@@ -137,7 +139,7 @@ void rwkv6_forward_fp32(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& stat
     need_btc(r, "r", B, T, C, F32, r); need_btc(k, "k", B, T, C, F32, r); need_btc(v, "v", B, T, C, F32, r);
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", F32, r); need_btc(y, "y", B, T, C, F32, r);
     TORCH_CHECK(state.numel() == B * H * 64 * 64, "state must be [B,H,N,N] ([H,N,N] for B = 1)");
-    const c10::hip::HIPGuard guard(r.device());
+    const DeviceGuard guard(r.device());
     ok(rwkv6_cuda_forward_fp32(B, T, C, H, state.data_ptr<float>(), r.data_ptr<float>(), k.data_ptr<float>(), v.data_ptr<float>(),
                                w.data_ptr<float>(), u.data_ptr<float>(), y.data_ptr<float>(), stream_of(r)), "rwkv6 forward_fp32");
 }

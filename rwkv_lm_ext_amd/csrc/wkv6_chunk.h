@@ -2,6 +2,18 @@
 #pragma once
 #include "wkv6_scan.h"
 
+// Diagnostic build (-DWKV6_STAMP, tools/ablate.sh): waves accumulate s_memtime cycles per phase into the buffer set through
+// wkv6_set_debug_buffer(); no stamp executes in the normal build.
+#ifdef WKV6_STAMP
+#define WKV6_T(var) do { __builtin_amdgcn_sched_barrier(0); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WKV6_ACC(k, t1, t0) stamp_acc[k] += (t1) - (t0)
+namespace wkv6 { extern unsigned long long* g_stamp_buffer; }
+#else
+#define WKV6_T(var) do { } while (0)
+#define WKV6_ACC(k, t1, t0) do { } while (0)
+#endif
+
 namespace wkv6 {
 namespace chunk {
 

@@ -105,6 +105,9 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         io4<bf16_t>::store(out + idx, o);
     };
 
+#ifdef WKV6_STAMP
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+#endif
     // ---- producer role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block pb
     const int c8i = lane & 7, tq = lane >> 3;
     const int ch0 = 32 * half + 4 * c8i;
@@ -236,11 +239,21 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         }
         __syncthreads();
         for (int grp = ngrp - 1; grp >= 0; --grp) {
+            WKV6_T(ts0);
+#ifdef WKV6_STAMP
+            asm volatile("" :: "v"(pr[0].x), "v"(pk[0].x), "v"(pv[0].x), "v"(pg[0].x), "v"(pw[0].x), "v"(pr[1].x), "v"(pk[1].x),
+                         "v"(pv[1].x), "v"(pg[1].x), "v"(pw[1].x));      // wait for the loads here
+#endif
+            WKV6_T(ts1);
             if (grp > 0) {
                 prep_group(grp - 1);
+                WKV6_T(ts2);
                 if (grp > 1) load_group(grp - 2);
             }
+            WKV6_T(ts3);
             __syncthreads();
+            WKV6_T(ts4);
+            WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3);
         }
     } else
     if (rowrole) {
@@ -256,6 +269,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
+            WKV6_T(ts0);
             {   // stage-entry forward state (dumped in the forward kernel's register order)
                 const float* const ck = a.ckpt + ((long)blockIdx.x * nstmax + grp) * (HEAD * HEAD);
                 // element S[i = 16wv + x][j]: forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), reg i&3
@@ -272,6 +286,10 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
                 }
             }
+#ifdef WKV6_STAMP
+            asm volatile("" :: "v"(ST[0][0][0]), "v"(ST[0][1][0]), "v"(ST[0][2][0]), "v"(ST[0][3][0]), "v"(ST[0][0][3]), "v"(ST[0][3][3]));
+#endif
+            WKV6_T(ts1);
             const char* const buf = smem + (grp & 1) * BUF_BYTES;
 
             // ---- rebuild the entry state of block 1:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
@@ -295,6 +313,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                 }
             }
 
+            WKV6_T(ts2);
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
             //      Four independent blocks => many instructions in flight.
@@ -379,6 +398,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     }
                 }
             }
+            WKV6_T(ts3);
             // ---- chain: only the work that needs G
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
@@ -453,7 +473,10 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * Oi[jt][q]);
             }
+            WKV6_T(ts4);
             __syncthreads();
+            WKV6_T(ts5);
+            WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3); WKV6_ACC(4, ts5, ts4);
         }
         if (a.gu) {
             float s4[4];
@@ -469,6 +492,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         for (int t = 0; t < 4; ++t) GJ[t] = f4v{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
+            WKV6_T(ts0);
             const char* const buf = smem + (grp & 1) * BUF_BYTES;
             // ---- pre-phase: everything that does not depend on G, stage-major over the 4 blocks so that many
             //      independent LDS reads / MFMAs are in flight (blocks past the end of the sequence are neutral)
@@ -526,6 +550,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     }
                 }
             }
+            WKV6_T(ts1);
             // ---- chain: only the work that needs G
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
@@ -568,7 +593,10 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * Og[blk][it][3]);
                 }
             }
+            WKV6_T(ts2);
             __syncthreads();
+            WKV6_T(ts3);
+            WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2);
         }
         if (a.gs) {   // dL/dS0, layout [j][i]
             bf16_t* const og = reinterpret_cast<bf16_t*>(a.gs) + ((long)b * a.H + h) * HEAD * HEAD;
@@ -579,6 +607,12 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             }
         }
     }
+#ifdef WKV6_STAMP
+    if (a.aux && lane == 0) {
+        unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)blockIdx.x * 16 + wid) * 8;
+        for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
+    }
+#endif
     if (a.zero_tail && !a.accumulate) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += 48) {
@@ -613,7 +647,13 @@ hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
         sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
         if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
     }
+#ifdef WKV6_STAMP
+    ScanArgs b = a;
+    b.aux = reinterpret_cast<float*>(g_stamp_buffer);
+    return b.wkind ? launch_bwd12_variant<true>(b, st) : launch_bwd12_variant<false>(b, st);
+#else
     return a.wkind ? launch_bwd12_variant<true>(a, st) : launch_bwd12_variant<false>(a, st);
+#endif
 }
 
 }  // namespace wkv6

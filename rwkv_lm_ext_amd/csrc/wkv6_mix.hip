@@ -17,7 +17,6 @@
 namespace wkv6 {
 namespace {
 
-constexpr int MAX_NS = 5;
 
 struct LerpArgs {
     int B, T, C, NS;

@@ -45,7 +45,7 @@ class WKV_6(torch.autograd.Function):
             _assert_inputs(C, H, r, k, v, w, u)
             ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
             ctx.save_for_backward(r, k, v, w, u)
-            # when a backward will follow, let the forward store its per-64-token state checkpoints (fp32, 4 B per
+            # when a backward will follow, let the forward store its per-32-token state checkpoints (fp32, 8 B per
             # token-channel) so the backward does not have to recompute them with a state pass
             ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
             return wkv6_op.forward_ex(r, k, v, w, u, H, ckpt=ctx.ckpt)
@@ -75,7 +75,8 @@ class WKV_6STATE(torch.autograd.Function):
             _assert_inputs(C, H, r, k, v, w, u, s)
             ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
             ctx.save_for_backward(r, k, v, w, u, s)
-            return wkv6_op.forward_ex(r, k, v, w, u, H, s0=s)
+            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
+            return wkv6_op.forward_ex(r, k, v, w, u, H, s0=s, ckpt=ctx.ckpt)
 
     @staticmethod
     def backward(ctx, gy):
@@ -84,7 +85,8 @@ class WKV_6STATE(torch.autograd.Function):
             gy = gy.contiguous()
             r, k, v, w, u, s = ctx.saved_tensors
             H, N = ctx.H, ctx.C // ctx.H
-            gr, gk, gv, gw, gu, gs = wkv6_op.backward_ex(r, k, v, w, u, gy, H, s0=s, want_gs=True)
+            gr, gk, gv, gw, gu, gs = wkv6_op.backward_ex(r, k, v, w, u, gy, H, s0=s, want_gs=True, ckpt=ctx.ckpt)
+            ctx.ckpt = None
             return (None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (H, N)), _sum_bf16(gs, (H, N, N)))
 
 
@@ -98,8 +100,9 @@ class WKV_6STATE_INFCTX(torch.autograd.Function):
             ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
             s_init = s.clone()
             ctx.save_for_backward(r, k, v, w, u, s_init)
+            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
             # s <- final state, written through the raw pointer exactly like the reference kernel does
-            return wkv6_op.forward_ex(r, k, v, w, u, H, s0=s_init, s_out=s)
+            return wkv6_op.forward_ex(r, k, v, w, u, H, s0=s_init, s_out=s, ckpt=ctx.ckpt)
 
     @staticmethod
     def backward(ctx, gy):
@@ -108,7 +111,8 @@ class WKV_6STATE_INFCTX(torch.autograd.Function):
             gy = gy.contiguous()
             r, k, v, w, u, s_init = ctx.saved_tensors
             H, N = ctx.H, ctx.C // ctx.H
-            gr, gk, gv, gw, gu, gs = wkv6_op.backward_ex(r, k, v, w, u, gy, H, s0=s_init, want_gs=True)
+            gr, gk, gv, gw, gu, gs = wkv6_op.backward_ex(r, k, v, w, u, gy, H, s0=s_init, want_gs=True, ckpt=ctx.ckpt)
+            ctx.ckpt = None
             # the reference sums gs over the batch to [H,N,N] although s is per sample (src/model.py:126);
             # the per-sample gradient is the mathematically correct one for a per-sample state
             return (None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (H, N)), gs)

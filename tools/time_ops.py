@@ -51,19 +51,21 @@ if args.only in ("both", "fwd"):
 if args.only in ("both", "bwd"):
     out["bwd_ms"] = round(run(bwd, args.iters), 4)
 print(os.environ.get("ABL_NAME", "default"), out, flush=True)
-if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wave phase cycles of one forward launch
+if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wave phase cycles of one backward launch
     import ctypes
     from rwkv_lm_ext_amd import _lib
     lib = _lib.load()
-    buf = torch.zeros(B * H * 16 * 4, dtype=torch.int64, device=dev)
+    buf = torch.zeros(B * H * 16 * 8, dtype=torch.int64, device=dev)
     lib.wkv6_set_debug_buffer.argtypes = [ctypes.c_void_p]
     lib.wkv6_set_debug_buffer.restype = None
     lib.wkv6_set_debug_buffer(buf.data_ptr())
-    fwd()
+    bwd()
     torch.cuda.synchronize()
-    d = buf.view(B * H, 16, 4).double().mean(0)         # average over workgroups: [wave][phase]
-    ng = (T + 63) // 64
-    print("per-group cycles per wave (avg over workgroups): consumers = [finish, body, barrier], producers = [load wait, prep+issue, barrier, prep only]")
-    for wv in range(16):
-        print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / ng):8.0f}" for k in range(4)))
-
+    d = buf.view(B * H, 16, 8).double().mean(0)         # average over workgroups: [wave][phase]
+    ns = (T + 31) // 32
+    print("backward, cycles per 32-token stage and wave (avg over workgroups):")
+    print("  row waves 0-3  = [ckpt load, rebuild, pre-phase, chain, barrier]")
+    print("  col waves 4-7  = [pre-phase, chain, barrier]")
+    print("  producers 8-11 = [load wait, prep, load issue, barrier]")
+    for wv in range(12):
+        print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / ns):8.0f}" for k in range(5)))
