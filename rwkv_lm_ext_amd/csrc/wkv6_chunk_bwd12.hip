@@ -44,6 +44,8 @@ constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float 
 constexpr int BBLK_BYTES = BOFF_COEF + 128;
 constexpr int STG = 32, SBLK = STG / BLK;                             // tokens / blocks per stage
 constexpr int BUF_BYTES = SBLK * BBLK_BYTES;                           // one stage image; two of them
+constexpr int CKQ_OFF = 2 * BUF_BYTES;                                 // float [4 row waves][16][64]: next stage's checkpoint (LDS-DMA)
+constexpr int BWD12_LDS = CKQ_OFF + 4 * 4096;
 
 // s_nop 1: a VALU write of a VGPR must be 2 wait states ahead of a DPP read of it, and nothing inside an asm string is padded
 #define WKV6_DPP_ACC(x, ctrl) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
@@ -69,7 +71,7 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 template <bool W_RAW>
 __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][BBLK_BYTES]
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][BBLK_BYTES] | checkpoint queue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool rowrole = wid < 4, producer = wid >= 8;
@@ -266,26 +268,56 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 #pragma unroll
         for (int t = 0; t < 4; ++t) GI[t] = f4v{0.f, 0.f, 0.f, 0.f};
         float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // Checkpoint of stage `stg` -> this lane's row of the forward state.  The forward dumps its registers as they stand:
+        // element S[i][j] sits in forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), register i&3 --
+        // four consecutive key rows i per float4, value column j on the lane -- while this wave needs key row i on the lane and
+        // four consecutive columns j in the registers.  Lane (x = 4m + p, g) therefore fetches, per column tile jt, the float4
+        // {S[16wv + 4m + r][tile_ch(jt) + 8g + p], r = 0..3} (16 contiguous bytes; the four lanes of a quad fetch 64 contiguous
+        // bytes) and the 4x4 transpose inside each quad happens in the LDS addressing of the read-back.
+        // The bytes travel global -> LDS directly (LDS-DMA, no VGPRs), one stage ahead: a wave requests the next stage's
+        // checkpoint into its private 4 KB of LDS right after it has read the current one back, so the global latency that
+        // used to open every stage runs under the stage's work.  Only the issuing wave reads its region, behind its own
+        // s_waitcnt vmcnt(0) -- no cross-wave ordering involved.
+        char* const qreg = smem + CKQ_OFF + wv * 4096;
+        const unsigned qbase = __builtin_amdgcn_readfirstlane(
+            (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)qreg));   // LDS byte address, wave-uniform
+        auto request_ckpt = [&](int stg) {
+            const float* const ck = a.ckpt + ((long)blockIdx.x * nstmax + stg) * (HEAD * HEAD);
+            const int i0 = 16 * wv + (x & 12), p = x & 3;
+            const int fit = 2 * (i0 >> 5) + ((i0 >> 2) & 1), fg = (i0 >> 3) & 3;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const int j_ = tile_ch(jt) + 8 * g + p;
+                const float* src = ck + (((j_ >> 4) * 4 + fit) * 64 + 16 * fg + (j_ & 15)) * 4;
+                // Inline asm on purpose: the builtin makes hipcc drain the DMA (s_waitcnt vmcnt(0)) before the next LDS read
+                // of ANY part of the LDS array, i.e. immediately.  LDS destination = M0 + lane * 16; M0 is compiler-reserved,
+                // so it is saved, set and restored inside the one statement that uses it.
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(qbase + (unsigned)(jt * 1024)) : "memory");
+            }
+        };
+        if (ngrp > 0) request_ckpt(ngrp - 1);
 
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             WKV6_T(ts0);
-            {   // stage-entry forward state (dumped in the forward kernel's register order)
-                const float* const ck = a.ckpt + ((long)blockIdx.x * nstmax + grp) * (HEAD * HEAD);
-                // element S[i = 16wv + x][j]: forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), reg i&3
-                const int i_ = 16 * wv + x;
-                const int fit = 2 * (i_ >> 5) + ((i_ >> 2) & 1), fg = (i_ >> 3) & 3, fq = i_ & 3;
+            // stage-entry forward state: read back what this wave requested a stage ago, then request the next one.
+            // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here (issued a whole stage ago --
+            // and the stage barrier's release fence has already drained this wave's vector-memory queue -- so this is free).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    float t4[4];
+            for (int jt = 0; jt < 4; ++jt) {
+                float t4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int j_ = tile_ch(jt) + 8 * g + q;
-                        t4[q] = ck[(((j_ >> 4) * 4 + fit) * 64 + 16 * fg + (j_ & 15)) * 4 + fq];
-                    }
-                    ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
-                }
+                for (int q = 0; q < 4; ++q)   // register p of the lane that fetched column q of this quad
+                    t4[q] = *reinterpret_cast<const float*>(qreg + jt * 1024 + (16 * g + (x & 12) + q) * 16 + (x & 3) * 4);
+                ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the values are in registers before the region is reused
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp > 0) request_ckpt(grp - 1);
 #ifdef WKV6_STAMP
             asm volatile("" :: "v"(ST[0][0][0]), "v"(ST[0][1][0]), "v"(ST[0][2][0]), "v"(ST[0][3][0]), "v"(ST[0][0][3]), "v"(ST[0][3][3]));
 #endif
@@ -627,7 +659,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 
 template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (size_t)BUF_BYTES;
+    constexpr size_t lds = BWD12_LDS;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static LdsAttrOnce attr;                   // per instantiation and device
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW>), lds)) return e;
