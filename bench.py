@@ -221,11 +221,13 @@ def main():
         mask = (torch.arange(T, device=dev).view(1, T) < (lens.view(B, 1) - 1)).to(torch.int32).contiguous()
         tokens = int(lens.clamp(max=T).sum().item())
 
+        bi_ws = wkv6_op.bi_new_workspace(B, T, C, H, dev)      # as WKV_6_BI keeps it from forward to backward
+
         def fwd():
-            wkv6_op.bi_forward_ex(mask, r, k, v, w, u, H)
+            wkv6_op.bi_forward_ex(mask, r, k, v, w, u, H, ws=bi_ws)
 
         def bwd():
-            wkv6_op.bi_backward_ex(mask, r, k, v, w, u, gy, H)
+            wkv6_op.bi_backward_ex(mask, r, k, v, w, u, gy, H, ws=bi_ws)
 
     from rwkv_lm_ext_amd.dp import timed_steps
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]

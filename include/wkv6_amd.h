@@ -86,8 +86,11 @@ enum {
     WKV6_IO_F32 = 2,        /* every bf16 tensor is fp32 instead (numerics tests) */
     WKV6_S0_PER_BATCH = 4,  /* s0 is [B,H,N,N] (infctx) instead of [H,N,N] (state) */
     WKV6_ALGO_SCAN = 16,    /* force the exact token-serial kernels            */
-    WKV6_CKPT_VALID = 32    /* backward: `workspace` already holds the checkpoints written by wkv6_forward_ckpt_ex
-                               for the same inputs, so the backward skips its own state pass */
+    WKV6_CKPT_VALID = 32,   /* backward: `workspace` already holds the checkpoints written by wkv6_forward_ckpt_ex
+                               (wkv6_bi: by wkv6bi_forward_ex with WKV6_BI_KEEP_CKPT) for the same inputs, so the backward
+                               skips its own state pass(es) */
+    WKV6_BI_KEEP_CKPT = 64  /* wkv6bi_forward_ex: also store the state checkpoints of both scans in `workspace` (which the
+                               caller then hands to wkv6bi_backward_ex with WKV6_CKPT_VALID) */
 };
 /* Bytes of scratch the backward needs (the forward needs none). */
 size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H);

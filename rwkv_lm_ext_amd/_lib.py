@@ -44,7 +44,7 @@ SIGNATURES = {
 }
 
 # flags of include/wkv6_amd.h
-W_EW_F32, W_RAW, IO_F32, S0_PER_BATCH, ALGO_SCAN, CKPT_VALID = 0, 1, 2, 4, 16, 32
+W_EW_F32, W_RAW, IO_F32, S0_PER_BATCH, ALGO_SCAN, CKPT_VALID, BI_KEEP_CKPT = 0, 1, 2, 4, 16, 32, 64
 
 ERRORS = {-1: "WKV6_EINVAL (shape: need C == H*64 and B,T,C,H >= 1)", -2: "WKV6_ENULL (null pointer)",
           -3: "WKV6_EWORKSPACE (workspace too small / allocation failed)", -4: "WKV6_EUNSUPPORTED"}

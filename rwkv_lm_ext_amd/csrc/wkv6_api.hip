@@ -119,11 +119,27 @@ size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H)
     const size_t chunk = chunk_ckpt_floats(B, T, H) * sizeof(float);
     return align_up(scan > chunk ? scan : chunk);
 }
+// wkv6_bi workspace: lens | checkpoints / scratch of the forward-direction scan | ... of the reverse-direction scan |
+//                    4 fp32 [B,T,C] side buffers (the forward uses the first one for y, the backward all four)
+struct BiWorkspace {
+    int* lens;
+    float* scan[2];
+    float* side[4];
+};
+static size_t bi_side_bytes(int B, int T, int C) { return align_up((size_t)B * T * C * sizeof(float)); }
+static BiWorkspace bi_carve(void* workspace, int B, int T, int C, int H)
+{
+    char* p = reinterpret_cast<char*>(workspace);
+    BiWorkspace w;
+    w.lens = reinterpret_cast<int*>(p);
+    p += align_up((size_t)B * sizeof(int));
+    for (int i = 0; i < 2; ++i) { w.scan[i] = reinterpret_cast<float*>(p); p += wkv6_backward_workspace_bytes(B, T, C, H); }
+    for (int i = 0; i < 4; ++i) { w.side[i] = reinterpret_cast<float*>(p); p += bi_side_bytes(B, T, C); }
+    return w;
+}
 size_t wkv6bi_workspace_bytes(int B, int T, int C, int H)
 {
-    // lens | backward workspace (forward: the fp32 y side buffer lives here) | 4 fp32 [B,T,C] gradient side buffers
-    return align_up((size_t)B * sizeof(int)) + wkv6_backward_workspace_bytes(B, T, C, H) +
-           4 * align_up((size_t)B * T * C * sizeof(float));
+    return align_up((size_t)B * sizeof(int)) + 2 * wkv6_backward_workspace_bytes(B, T, C, H) + 4 * bi_side_bytes(B, T, C);
 }
 
 int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
@@ -192,19 +208,21 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
     } else if (workspace_bytes < need) {
         return WKV6_EWORKSPACE;
     }
-    float* yf32 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * sizeof(int)));
+    const BiWorkspace ws = bi_carve(workspace, B, T, C, H);
     if (!lens) {
-        int* l = reinterpret_cast<int*>(workspace);
-        hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, l, T);
-        lens = l;
+        hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, ws.lens, T);
+        lens = ws.lens;
     }
+    const bool keep = (flags & WKV6_BI_KEEP_CKPT) && !(flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN));
     ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
     a.y = y;
-    a.y_f32 = yf32;                           // the two halves are summed in fp32 and rounded once
+    a.y_f32 = ws.side[0];                     // the two halves are summed in fp32 and rounded once
     a.lens = lens;
     a.zero_tail = 1;                          // y[t > L_b] = 0 (the reference leaves it uninitialised, Q2)
+    a.ckpt = keep ? ws.scan[0] : nullptr;
     if (hipError_t e = run_fwd(a, flags, st)) return (int)e;
     a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0;   // cuda/wkv6_bi_cuda.cu:71-111
+    a.ckpt = keep ? ws.scan[1] : nullptr;
     return to_rc(run_fwd(a, flags, st));
 }
 
@@ -223,11 +241,10 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
     } else if (workspace_bytes < need) {
         return WKV6_EWORKSPACE;
     }
-    int* l = reinterpret_cast<int*>(workspace);
-    float* aux = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * sizeof(int)));
+    const BiWorkspace ws = bi_carve(workspace, B, T, C, H);
     if (!lens) {
-        hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, l, T);
-        lens = l;
+        hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, ws.lens, T);
+        lens = ws.lens;
     }
     ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
     a.gy = gy; a.gr = gr; a.gk = gk; a.gv = gv; a.gw = gw; a.gu = gu;
@@ -236,12 +253,11 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
     if (!(flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN))) {
         // chunked bf16 path: the first half goes to fp32 side buffers, the second adds it and rounds once
         // (the reference accumulates `_gr[t] += F(gr)` in bf16, cuda/wkv6_bi_cuda.cu:199-200)
-        char* side = reinterpret_cast<char*>(aux) + wkv6_backward_workspace_bytes(B, T, C, H);
-        for (int i = 0; i < 4; ++i) a.g_f32[i] = reinterpret_cast<float*>(side + i * align_up((size_t)B * T * C * sizeof(float)));
+        for (int i = 0; i < 4; ++i) a.g_f32[i] = ws.side[i];
     }
-    if (hipError_t e = run_bwd(a, flags, aux, st)) return (int)e;                    // adjoint of the forward scan
+    if (hipError_t e = run_bwd(a, flags, ws.scan[0], st)) return (int)e;             // adjoint of the forward scan
     a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0; a.gu = nullptr;   // adjoint of the reverse scan
-    return to_rc(run_bwd(a, flags, aux, st));
+    return to_rc(run_bwd(a, flags, ws.scan[1], st));
 }
 
 // ---- reference-signature entry points ------------------------------------------------------------

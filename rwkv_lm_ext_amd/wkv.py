@@ -139,7 +139,9 @@ class WKV_6_BI(torch.autograd.Function):
             ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
             ctx.mask = mask
             ctx.save_for_backward(r, k, v, w, u)
-            return wkv6_op.bi_forward_ex(mask, r, k, v, w, u, H)
+            # when a backward will follow, both scans leave their state checkpoints in the workspace
+            ctx.ws = wkv6_op.bi_new_workspace(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
+            return wkv6_op.bi_forward_ex(mask, r, k, v, w, u, H, ws=ctx.ws)
 
     @staticmethod
     def backward(ctx, gy):
@@ -147,7 +149,8 @@ class WKV_6_BI(torch.autograd.Function):
             assert gy.dtype == torch.bfloat16
             gy = gy.contiguous()
             r, k, v, w, u = ctx.saved_tensors
-            gr, gk, gv, gw, gu = wkv6_op.bi_backward_ex(ctx.mask, r, k, v, w, u, gy, ctx.H)
+            gr, gk, gv, gw, gu = wkv6_op.bi_backward_ex(ctx.mask, r, k, v, w, u, gy, ctx.H, ws=ctx.ws)
+            ctx.ws = None
             return (None, None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (ctx.H, ctx.C // ctx.H)))
 
 

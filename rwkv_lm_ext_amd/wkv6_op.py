@@ -273,7 +273,15 @@ def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False, alg
     return gr, gk, gv, gw, gu, gs
 
 
-def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None):
+def bi_new_workspace(B, T, C, H, device):
+    """Workspace of the wkv6_bi pair: the forward's fp32 y side buffer, the state checkpoints of both scans (kept from
+    forward to backward when `ws` is passed to both calls) and the backward's four fp32 gradient side buffers."""
+    return torch.empty(_lib.load().wkv6bi_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=device)
+
+
+def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None, ws=None):
+    """ws: a bi_new_workspace() buffer the caller keeps for bi_backward_ex(..., ws=ws): the forward then stores the state
+    checkpoints of both scans in it and the backward skips its two state passes."""
     B, T, C = r.shape
     io = r.dtype
     btc = (B, T, C)
@@ -284,7 +292,10 @@ def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None):
     flags |= _lib.ALGO_SCAN if algo == "scan" else 0
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     y = torch.empty(btc, device=dev, dtype=io)
-    ws = torch.empty(_lib.load().wkv6bi_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+    if ws is not None:
+        flags |= _lib.BI_KEEP_CKPT
+    else:
+        ws = bi_new_workspace(B, T, C, H, dev)
     with torch.cuda.device(dev):
         rc = _lib.load().wkv6bi_forward_ex(B, T, C, H, _ptr(mask), None, _ptr(r), _ptr(k), _ptr(v), _ptr(w),
                                            _ptr(u), _ptr(y), _ptr(ws), ws.numel(), flags, _stream_ptr())
@@ -292,7 +303,8 @@ def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None):
     return y
 
 
-def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False, algo=None):
+def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False, algo=None, ws=None):
+    """ws: the workspace a preceding bi_forward_ex(..., ws=ws) on the same inputs filled (checkpoints valid)."""
     B, T, C = r.shape
     io = r.dtype
     btc = (B, T, C)
@@ -304,7 +316,10 @@ def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False, algo=None):
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
     gu = torch.empty((B, C), device=dev, dtype=io)
-    ws = torch.empty(_lib.load().wkv6bi_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+    if ws is not None and io == torch.bfloat16 and algo != "scan":
+        flags |= _lib.CKPT_VALID
+    elif ws is None:
+        ws = bi_new_workspace(B, T, C, H, dev)
     with torch.cuda.device(dev):
         rc = _lib.load().wkv6bi_backward_ex(B, T, C, H, _ptr(mask), None, _ptr(r), _ptr(k), _ptr(v), _ptr(w),
                                             _ptr(u), _ptr(gy), _ptr(gr), _ptr(gk), _ptr(gv), _ptr(gw), _ptr(gu),
