@@ -32,11 +32,11 @@ FWD_BYTES, BWD_BYTES = 10, 18   # per token-channel
 
 def measured_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_final_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE
+    (profiles/r02_final_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot read PMCs itself, so this is the
     number measured for the headline workload with the committed kernels; None for any other workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_final_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_final_pmc.json")) as f:
             return int(json.load(f)["kernels"][kernel]["hbm_bytes"])
     except Exception:
         return None

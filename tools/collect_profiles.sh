@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline block refers to.  Run on the GPU box from the repo root:
 #     bash tools/collect_profiles.sh gpurun_out/prof
-# then, back in the container:  python tools/aggregate_profiles.py gpurun_out/prof profiles/r01_final
+# then, back in the container:  python tools/aggregate_profiles.py gpurun_out/prof profiles/r02_final
 # (kernel-trace/stats and every --pmc group are separate runs; no sys/hip trace is combined with --pmc).
 set -e -o pipefail
 OUT=${1:-gpurun_out/prof}
@@ -17,4 +17,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
     i=$((i + 1))
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$ROOT/$OUT/pmc$i" -- $CMD > "$ROOT/$OUT/pmc$i.log" 2>&1 || echo "pmc group $i failed: $grp"
 done
+# kernel-trace statistics and bench lines of the other single-GPU workloads (BASELINE configs[2], [4])
+for wl in bi infctx; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$wl" -- python3 $ROOT/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu > "$ROOT/$OUT/stats_$wl.log" 2>&1 || echo "stats $wl failed"
+    python3 $ROOT/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu > "$ROOT/$OUT/bench_$wl.json" 2> /dev/null
+done
+python3 $ROOT/bench.py --steps 100 --warmup 20 > "$ROOT/$OUT/bench_wkv6.json" 2> /dev/null
 echo done
