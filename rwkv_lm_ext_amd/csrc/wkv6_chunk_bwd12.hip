@@ -176,8 +176,11 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             if (c8i == 0) *reinterpret_cast<float*>(bb + BOFF_COEF + (half * 16 + tok) * 4) = part;
             *reinterpret_cast<uint2*>(row + B_V * ARR) = pv[tt];
             *reinterpret_cast<uint2*>(row + B_GY * ARR) = pg[tt];
-            *reinterpret_cast<uint2*>(row + B_R * ARR) = pr[tt];
-            *reinterpret_cast<uint2*>(row + B_K * ARR) = pk[tt];
+            // raw r, k: only read as (token x, 4 channels) uint2 by the row waves; tokens >= 8 keep their 16-byte units swapped
+            // in pairs so that rows x and x + 8 (same bank at the 160-B stride) do not collide in that read
+            char* const rowz = bb + tok * RSB + ((ch0 * 2) ^ ((tok & 8) << 1));
+            *reinterpret_cast<uint2*>(rowz + B_R * ARR) = pr[tt];
+            *reinterpret_cast<uint2*>(rowz + B_K * ARR) = pk[tt];
             *reinterpret_cast<float4*>(bb + BOFF_LW + tok * FRS + ch0 * 4) = make_float4(lwe[0], lwe[1], lwe[2], lwe[3]);
         }
         float pre[4], c8[4], c16[4];
@@ -271,9 +274,12 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         // Checkpoint of stage `stg` -> this lane's row of the forward state.  The forward dumps its registers as they stand:
         // element S[i][j] sits in forward wave j>>4, tile 2(i>>5) + ((i>>2)&1), lane 16((i>>3)&3) + (j&15), register i&3 --
         // four consecutive key rows i per float4, value column j on the lane -- while this wave needs key row i on the lane and
-        // four consecutive columns j in the registers.  Lane (x = 4m + p, g) therefore fetches, per column tile jt, the float4
-        // {S[16wv + 4m + r][tile_ch(jt) + 8g + p], r = 0..3} (16 contiguous bytes; the four lanes of a quad fetch 64 contiguous
-        // bytes) and the 4x4 transpose inside each quad happens in the LDS addressing of the read-back.
+        // four consecutive columns j in the registers.  A fetch lane therefore loads, per column tile jt, one float4
+        // {S[16wv + 4m + r][tile_ch(jt) + 8g + p], r = 0..3} (16 contiguous bytes; the lanes with p = 0..3 cover 64 contiguous
+        // bytes) and the 4x4 transpose happens in the LDS addressing of the read-back: lane (x = 4m + p', g) picks dword p' of
+        // the float4s (m, g, p = 0..3).  The DMA puts fetch lane F's float4 at byte 16 F of the region, so WHICH lane fetches
+        // (m, g, p) decides the banks of the read-back: F = 8 (4 (g>>1) + p) + 4 (g&1) + m makes the 32 lanes of a read-back
+        // group (g&1, m, p') hit the 32 banks once each (the obvious F = 16 g + 4 m + p is 4-way conflicted: tools/lds_conflicts.py).
         // The bytes travel global -> LDS directly (LDS-DMA, no VGPRs), one stage ahead: a wave requests the next stage's
         // checkpoint into its private 4 KB of LDS right after it has read the current one back, so the global latency that
         // used to open every stage runs under the stage's work.  Only the issuing wave reads its region, behind its own
@@ -283,11 +289,12 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)qreg));   // LDS byte address, wave-uniform
         auto request_ckpt = [&](int stg) {
             const float* const ck = a.ckpt + ((long)blockIdx.x * nstmax + stg) * (HEAD * HEAD);
-            const int i0 = 16 * wv + (x & 12), p = x & 3;
+            const int fm = lane & 3, fgl = (lane >> 2) & 1, fp = (lane >> 3) & 3, fgh = lane >> 5;   // this lane as a fetch lane
+            const int i0 = 16 * wv + 4 * fm, gq = 2 * fgh + fgl;
             const int fit = 2 * (i0 >> 5) + ((i0 >> 2) & 1), fg = (i0 >> 3) & 3;
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
-                const int j_ = tile_ch(jt) + 8 * g + p;
+                const int j_ = tile_ch(jt) + 8 * gq + fp;
                 const float* src = ck + (((j_ >> 4) * 4 + fit) * 64 + 16 * fg + (j_ & 15)) * 4;
                 // Inline asm on purpose: the builtin makes hipcc drain the DMA (s_waitcnt vmcnt(0)) before the next LDS read
                 // of ANY part of the LDS array, i.e. immediately.  LDS destination = M0 + lane * 16; M0 is compiler-reserved,
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                              : "=&s"(keep) : "v"(src), "s"(qbase + (unsigned)(jt * 1024)) : "memory");
             }
         };
+        const int qrd = (8 * (4 * (g >> 1)) + 4 * (g & 1) + (x >> 2)) * 16 + (x & 3) * 4;   // read-back: + jt 1024 + q 128
         if (ngrp > 0) request_ckpt(ngrp - 1);
 
         __syncthreads();                                          // first stage image is ready
@@ -311,8 +319,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             for (int jt = 0; jt < 4; ++jt) {
                 float t4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)   // register p of the lane that fetched column q of this quad
-                    t4[q] = *reinterpret_cast<const float*>(qreg + jt * 1024 + (16 * g + (x & 12) + q) * 16 + (x & 3) * 4);
+                for (int q = 0; q < 4; ++q)   // dword x&3 of the float4 fetched for column q
+                    t4[q] = *reinterpret_cast<const float*>(qreg + jt * 1024 + q * 128 + qrd);
                 ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the values are in registers before the region is reused
@@ -409,8 +417,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                 {   // gr, a_t, gu: lane = token x, channels ch .. ch+3
                     const int ch = 16 * wv + 4 * g;
                     const float4 fr4 = *reinterpret_cast<const float4*>(bb + BOFF_FR + x * FRS + ch * 4);
-                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
-                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
+                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
+                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
                     const float frv[4] = {fr4.x, fr4.y, fr4.z, fr4.w};
                     const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
                     const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
@@ -469,8 +477,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     const int ch = 16 * wv + 4 * g;
                     const float4 fk4 = *reinterpret_cast<const float4*>(bb + BOFF_FK + x * FRS + ch * 4);
                     const float4 lw4 = *reinterpret_cast<const float4*>(bb + BOFF_LW + x * FRS + ch * 4);
-                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ch * 2);
-                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ch * 2);
+                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
+                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
                     const float fkv[4] = {fk4.x, fk4.y, fk4.z, fk4.w}, lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
                     const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
                     const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
