@@ -41,23 +41,23 @@ constexpr int BOFF_E8 = BOFF_LW + BLK * FRS;                           // float 
 constexpr int BOFF_E16 = BOFF_E8 + 256;
 constexpr int BOFF_E16M8 = BOFF_E16 + 256;
 constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float [2][16]  per-half sum_i r u k
-constexpr int BBLK_BYTES = BOFF_COEF + 128;
+constexpr int BOFF_VG = BOFF_COEF + 128;                               // float [2][16]  per-half gy_a . v_a
+constexpr int BBLK_BYTES = BOFF_VG + 128;
 constexpr int STG = 32, SBLK = STG / BLK;                             // tokens / blocks per stage
 constexpr int BUF_BYTES = SBLK * BBLK_BYTES;                           // one stage image; two of them
 constexpr int CKQ_OFF = 2 * BUF_BYTES;                                 // float [4 row waves][16][64]: next stage's checkpoint (LDS-DMA)
 constexpr int BWD12_LDS = CKQ_OFF + 4 * 4096;
 
-// s_nop 1: a VALU write of a VGPR must be 2 wait states ahead of a DPP read of it, and nothing inside an asm string is padded
-#define WKV6_DPP_ACC(x, ctrl) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
+// One step of four independent in-row suffix sums: x[q] += x[q] of the lane `ctrl` names (lanes without a source keep their
+// value: DPP disables them).  Single v_add_f32_dpp instructions (the builtin gives v_mov_dpp + v_add).  A VALU write of a VGPR
+// must be 2 wait states ahead of a DPP read of it and nothing inside an asm string is padded by the compiler: the four
+// chains are interleaved so that they keep that distance among themselves, and each step opens with s_nop 1 for whatever
+// the compiler may have placed in front of it (a register copy, the subtraction that produced x).
+#define WKV6_DPP_ACC4(x, ctrl) asm("s_nop 1\n\t" \
+    "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf" \
+    : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
 
-__device__ __forceinline__ float pick4(const f4v& v, int s)
-{
-    float o = v[0];
-    o = s == 1 ? v[1] : o;
-    o = s == 2 ? v[2] : o;
-    o = s == 3 ? v[3] : o;
-    return o;
-}
 // split a C-layout tile pair (8 floats) into the hi / lo bf16x8 fragments of one k-step
 __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4], b8v& hi, b8v& lo)
 {
@@ -173,7 +173,17 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             part += __shfl_xor(part, 4);                                  // the 8 lanes that share this token
             const int tok = 2 * tq + tt;
             char* const row = bb + tok * RSB + ch0 * 2;
-            if (c8i == 0) *reinterpret_cast<float*>(bb + BOFF_COEF + (half * 16 + tok) * 4) = part;
+            // vg_a = gy_a . v_a, this half's 32 channels (exact bf16 products, fp32 sums): the row waves' diagonal of dA
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            float pvg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pg[tt].x), __builtin_bit_cast(bf2, pv[tt].x), 0.f, false);
+            pvg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pg[tt].y), __builtin_bit_cast(bf2, pv[tt].y), pvg, false);
+            pvg += dpp_mov<DPP_XOR1>(pvg);
+            pvg += dpp_mov<DPP_XOR2>(pvg);
+            pvg += __shfl_xor(pvg, 4);
+            if (c8i == 0) {
+                *reinterpret_cast<float*>(bb + BOFF_COEF + (half * 16 + tok) * 4) = part;
+                *reinterpret_cast<float*>(bb + BOFF_VG + (half * 16 + tok) * 4) = pvg;
+            }
             *reinterpret_cast<uint2*>(row + B_V * ARR) = pv[tt];
             *reinterpret_cast<uint2*>(row + B_GY * ARR) = pg[tt];
             // raw r, k: only read as (token x, 4 channels) uint2 by the row waves; tokens >= 8 keep their 16-byte units swapped
@@ -306,14 +316,19 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         };
         const int qrd = (8 * (4 * (g >> 1)) + 4 * (g & 1) + (x >> 2)) * 16 + (x & 3) * 4;   // read-back: + jt 1024 + q 128
         if (ngrp > 0) request_ckpt(ngrp - 1);
+        const bool plain_stores = !a.accumulate && !a.g_f32[0] && !a.g_f32[1] && !a.g_f32[3];   // emit = one store, no load
+        int later = 0;
 
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             WKV6_T(ts0);
             // stage-entry forward state: read back what this wave requested a stage ago, then request the next one.
-            // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here (issued a whole stage ago --
-            // and the stage barrier's release fence has already drained this wave's vector-memory queue -- so this is free).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here.  It was issued a whole stage ago,
+            // but this wave's gradient stores of that stage were issued after it and vmcnt retires in order: waiting for
+            // vmcnt(0) would also wait for the acknowledgement of stores issued a few hundred cycles ago.  When the previous
+            // stage issued exactly its six plain stores (gr, gk, gw of two blocks), wait until only those are outstanding.
+            if (later == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
@@ -326,6 +341,9 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the values are in registers before the region is reused
             __builtin_amdgcn_sched_barrier(0);
             if (grp > 0) request_ckpt(grp - 1);
+#ifndef WKV6_VMCNT0                                                  // (ablation switch: always drain)
+            later = (plain_stores && (grp + 1) * STG <= ntok) ? 6 : 0;   // vector-memory instructions this stage issues after the request
+#endif
 #ifdef WKV6_STAMP
             asm volatile("" :: "v"(ST[0][0][0]), "v"(ST[0][1][0]), "v"(ST[0][2][0]), "v"(ST[0][3][0]), "v"(ST[0][0][3]), "v"(ST[0][3][3]));
 #endif
@@ -372,8 +390,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     dA_ab = mfma32(gyr[s], vr, dA_ab);           // [row a][col b]: lane col b = x, rows a = 4g+q
                     dA_ba = mfma32(vr, gyr[s], dA_ba);           // [row b][col a]: lane col a = x, rows b = 4g+q
                 }
-                // vg_x = dA[x][x]: held by lane (x, g = x>>2) in register x&3
-                const float vg = __shfl(pick4(dA_ba, x & 3), 16 * (x >> 2) + x);
+                // vg_x = dA[x][x] = gy_x . v_x: the producers' two half sums
+                const float vg = *reinterpret_cast<const float*>(bb + BOFF_VG + x * 4) + *reinterpret_cast<const float*>(bb + BOFF_VG + 64 + x * 4);
                 vgs[blk] = vg;
                 float dab[4], dba[4];
 #pragma unroll
@@ -483,20 +501,23 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
                     const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
                     const float vg = vgs[blk];
-                    float o_gk[4], o_gw[4];
+                    float o_gk[4], o_gw[4], bt[4], dl[4], sfx[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float dk = fkv[q] * acck[q];
                         o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
-                        const float bt = kv[q] * dk;
-                        const float dl = at[blk][q] - bt;
-                        float sfx = dl;                           // inclusive suffix sum over the later tokens of the row:
-                        WKV6_DPP_ACC(sfx, "row_shl:1");           // one v_add_f32_dpp per step (lanes without a source keep
-                        WKV6_DPP_ACC(sfx, "row_shl:2");           // their value: DPP disables them)
-                        WKV6_DPP_ACC(sfx, "row_shl:4");
-                        WKV6_DPP_ACC(sfx, "row_shl:8");
-                        const float total = __shfl(sfx, lane & 48);
-                        o_gw[q] = (Rc[q] + (sfx - dl) - bt) * lwv[q];
+                        bt[q] = kv[q] * dk;
+                        dl[q] = at[blk][q] - bt[q];
+                        sfx[q] = dl[q];
+                    }
+                    WKV6_DPP_ACC4(sfx, "row_shl:1");      // inclusive suffix sums over the later tokens of the row
+                    WKV6_DPP_ACC4(sfx, "row_shl:2");
+                    WKV6_DPP_ACC4(sfx, "row_shl:4");
+                    WKV6_DPP_ACC4(sfx, "row_shl:8");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float total = dpp_mov<DPP_BCAST0>(sfx[q]);   // token 0 of the row holds the block total
+                        o_gw[q] = (Rc[q] + (sfx[q] - dl[q]) - bt[q]) * lwv[q];
                         Rc[q] += total;
                     }
                     const int p = grp * STG + blk * BLK + x;

@@ -55,6 +55,7 @@ constexpr int DPP_XOR1 = 0xB1;       // quad_perm:[1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;       // quad_perm:[2,3,0,1]
 constexpr int DPP_ROR4 = 0x124;      // row_ror:4
 constexpr int DPP_ROR8 = 0x128;      // row_ror:8
+constexpr int DPP_BCAST0 = 0x150;    // row_newbcast:0 (lane 0 of each row of 16 to the whole row)
 
 // Sum over the 16 lanes of a DPP row (lanes 16q..16q+15).  Every lane gets the total.
 __device__ __forceinline__ float row_sum16(float x)
