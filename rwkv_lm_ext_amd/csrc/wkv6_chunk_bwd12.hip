@@ -338,12 +338,6 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     t4[q] = *reinterpret_cast<const float*>(qreg + jt * 1024 + q * 128 + qrd);
                 ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the values are in registers before the region is reused
-            __builtin_amdgcn_sched_barrier(0);
-            if (grp > 0) request_ckpt(grp - 1);
-#ifndef WKV6_VMCNT0                                                  // (ablation switch: always drain)
-            later = (plain_stores && (grp + 1) * STG <= ntok) ? 6 : 0;   // vector-memory instructions this stage issues after the request
-#endif
 #ifdef WKV6_STAMP
             asm volatile("" :: "v"(ST[0][0][0]), "v"(ST[0][1][0]), "v"(ST[0][2][0]), "v"(ST[0][3][0]), "v"(ST[0][0][3]), "v"(ST[0][3][3]));
 #endif
@@ -371,6 +365,14 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                 }
             }
 
+            // Request the next stage's checkpoint.  The read-back above must have delivered before the region is overwritten:
+            // by now (the rebuild consumed the values) it has, the wait only states it; placed here rather than right after
+            // the read-back so that the LDS latency of the read-back runs under the rebuild's operand reads and MFMAs.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (grp > 0) request_ckpt(grp - 1);
+#ifndef WKV6_VMCNT0                                                  // (ablation switch: always drain)
+            later = (plain_stores && (grp + 1) * STG <= ntok) ? 6 : 0;   // vector-memory instructions this stage issues after the request
+#endif
             WKV6_T(ts2);
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
@@ -409,24 +411,26 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                 const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
                 const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
                 const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
-                const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
-                // gr accumulator [i_local = 4g+q][token x]
-                f4v accr = {0.f, 0.f, 0.f, 0.f};
+                // gr accumulator [i_local = 4g+q][token x].  E8 scales key rows = output rows here, so it is applied to the 4
+                // results instead of the 16 operand values (the state tiles are dead after this: split in place, no copy)
+                const float4 e8o = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (16 * wv + 4 * g) * 4);
+                f4v accs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     float t0[4], t1[4];
                     b8v hi, lo;                                  // k-slot (s, g, e) <-> value channel 32s + 8g + e
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q] * e8x; t1[q] = ST[blk][2 * s + 1][q] * e8x; }
+                    for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q]; t1[q] = ST[blk][2 * s + 1][q]; }
                     split8(t0, t1, hi, lo);
-                    accr = mfma32(hi, gyr[s], accr);
-                    accr = mfma32(lo, gyr[s], accr);
+                    accs = mfma32(hi, gyr[s], accs);
+                    accs = mfma32(lo, gyr[s], accs);
                 }
                 f4v accr16 = {0.f, 0.f, 0.f, 0.f};               // separate accumulator per MFMA shape (see wkv6_chunk.hip)
                 accr16 = mfma16(khf, dba_hi, accr16);            // sum_b Khat[b][i] dA[a][b]
                 accr16 = mfma16(khf, dba_lo, accr16);
                 accr16 = mfma16(klf, dba_hi, accr16);
-                accr += accr16;
+                const f4v accr = {fmaf(e8o.x, accs[0], accr16[0]), fmaf(e8o.y, accs[1], accr16[1]),
+                                  fmaf(e8o.z, accs[2], accr16[2]), fmaf(e8o.w, accs[3], accr16[3])};
                 f4v ak = {0.f, 0.f, 0.f, 0.f};
                 ak = mfma16(rhf_w, dab_hi, ak);                  // sum_a Rhat[a][i] dA[a][b]
                 ak = mfma16(rhf_w, dab_lo, ak);
