@@ -388,6 +388,9 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                 for (int s = 0; s < 2; ++s) {
                     const int off = x * RSB + (32 * s + 8 * g) * 2;
                     gyr[s] = ld_b8(bb + B_GY * ARR + off);
+#ifdef WKV6_ABL_DA                                               // timing-only ablation: three of the four row waves skip dA
+                    if (wv != 0) continue;
+#endif
                     const b8v vr = ld_b8(bb + B_V * ARR + off);
                     dA_ab = mfma32(gyr[s], vr, dA_ab);           // [row a][col b]: lane col b = x, rows a = 4g+q
                     dA_ba = mfma32(vr, gyr[s], dA_ba);           // [row b][col a]: lane col a = x, rows b = 4g+q
@@ -571,6 +574,9 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     sc[blk] = f4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
+#ifdef WKV6_ABL_SC                                               // timing-only ablation: three of the four column waves skip the scores
+                        if (wv != 0) continue;
+#endif
                         const int off = x * RSB + (32 * s + 8 * g) * 2;
                         const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
                         const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
