@@ -99,7 +99,7 @@ size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H);
 int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                     const void* w, const void* u, const void* s0, void* s_out, void* y,
                     unsigned flags, void* stream);
-/* Same as wkv6_forward_ex, and additionally stores the forward state at the entry of every 64-token group
+/* Same as wkv6_forward_ex, and additionally stores the forward state at the entry of every 32-token stage
  * (fp32, wkv6_backward_workspace_bytes() bytes) into `ckpt` -- the activation checkpoint a following
  * wkv6_backward_ex(..., workspace = ckpt, flags | WKV6_CKPT_VALID) consumes.  bf16 I/O, chunked kernels only;
  * returns WKV6_EUNSUPPORTED for WKV6_IO_F32 / WKV6_ALGO_SCAN. */
@@ -123,6 +123,22 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
                        size_t workspace_bytes, unsigned flags, void* stream);
 size_t wkv6bi_workspace_bytes(int B, int T, int C, int H);
 
+/* ---- partially reversed sequences: replaces the torch.gather round trips around the operator in the
+ * bidirectional compositions -- src/model_bi.py:331-348 (k, v reversed, y un-reversed) and src/model_ext.py:410-437 (every
+ * tensor reversed).  For batch row b, tokens [0, rev_n[b]) of the tensors named in rev_mask are read in reverse order (scan
+ * position p < rev_n[b] <-> token rev_n[b]-1-p, exactly reverse_x_idx of src/model_ext.py:410-417); positions >= rev_n[b]
+ * keep their place and ARE scanned (the sentence-embedding position sits right behind the reversed span).  WKV6_REV_Y applies
+ * to y (written through the map) and, in the backward, to gy; each gradient follows its tensor's bit.  rev_n: int32 [B] on
+ * the device.  bf16 I/O, chunked kernels only (WKV6_EUNSUPPORTED with WKV6_IO_F32 / WKV6_ALGO_SCAN).  ckpt may be NULL. */
+enum { WKV6_REV_R = 1, WKV6_REV_K = 2, WKV6_REV_V = 4, WKV6_REV_W = 8, WKV6_REV_Y = 16 };
+int wkv6_forward_rev_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v, const void* w,
+                        const void* u, void* y, void* ckpt, size_t ckpt_bytes, const int* rev_n, unsigned rev_mask,
+                        unsigned flags, void* stream);
+int wkv6_backward_rev_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v, const void* w,
+                         const void* u, const void* gy, void* gr, void* gk, void* gv, void* gw, void* gu,
+                         void* workspace, size_t workspace_bytes, const int* rev_n, unsigned rev_mask, unsigned flags,
+                         void* stream);
+
 /* ---- elementwise neighbours of the operator in the RWKV-6 time-mix block; bf16 only ----
  * ddlerp (src/model.py:435-448): xx = shift(x) - x; out[s] = x + xx * (maa[s] + m[s]), s < NS.
  *   x [B,T,C]; shifted0 [B,C] = token in front of each row (NULL: zero, nn.ZeroPad2d((0,0,1,-1))); m [NS,B,T,C] or NULL;
@@ -132,6 +148,13 @@ int wkv6_ddlerp_forward(int B, int T, int C, int NS, const void* x, const void* 
                         void* out, void* stream);
 int wkv6_ddlerp_backward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
                          const void* dout, void* dx, void* dm, float* dmaa_part, int nparts, void* stream);
+/* The same with the shift taken over the stream "first rev_n[b] tokens of row b reversed, the rest in place" while x, m, out
+ * stay in the original token order (row n2: the reversed half of src/model_ext.py:421-437 without gathering x).  rev_n: int32
+ * [B] on the device, NULL = plain shift. */
+int wkv6_ddlerp_rev_forward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
+                            const int* rev_n, void* out, void* stream);
+int wkv6_ddlerp_rev_backward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
+                             const int* rev_n, const void* dout, void* dx, void* dm, float* dmaa_part, int nparts, void* stream);
 /* gn_gate (src/model.py:462-468): out = GroupNorm_H(y; gamma, beta, eps) * g on rows of C = 64 H channels (nn.GroupNorm(H, C)
  * applied to [rows, C]); stats fp32 [rows,H,2] (mean, rstd) is written for the backward (may be NULL in inference).
  * backward: dy, dg [rows,C]; dgamma_part, dbeta_part fp32 [nparts,C] partial sums. */

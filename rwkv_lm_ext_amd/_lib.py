@@ -33,10 +33,14 @@ SIGNATURES = {
     "wkv6_forward_ex": (_I, [_I] * 4 + [_VP] * 8 + [_U, _VP]),
     "wkv6_forward_ckpt_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ, _U, _VP]),
     "wkv6_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
+    "wkv6_forward_rev_ex": (_I, [_I] * 4 + [_VP] * 7 + [_SZ, _VP, _U, _U, _VP]),
+    "wkv6_backward_rev_ex": (_I, [_I] * 4 + [_VP] * 12 + [_SZ, _VP, _U, _U, _VP]),
     "wkv6bi_forward_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ, _U, _VP]),
     "wkv6bi_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
     "wkv6_ddlerp_forward": (_I, [_I] * 4 + [_VP] * 6),
     "wkv6_ddlerp_backward": (_I, [_I] * 4 + [_VP] * 8 + [_I, _VP]),
+    "wkv6_ddlerp_rev_forward": (_I, [_I] * 4 + [_VP] * 7),
+    "wkv6_ddlerp_rev_backward": (_I, [_I] * 4 + [_VP] * 9 + [_I, _VP]),
     "wkv6_gn_gate_forward": (_I, [_L, _I, _I] + [_VP] * 4 + [_F] + [_VP] * 3),
     "wkv6_gn_gate_backward": (_I, [_L, _I, _I] + [_VP] * 10 + [_I, _VP]),
     "wkv6_selftest": (_I, [_VP]),
@@ -45,6 +49,7 @@ SIGNATURES = {
 
 # flags of include/wkv6_amd.h
 W_EW_F32, W_RAW, IO_F32, S0_PER_BATCH, ALGO_SCAN, CKPT_VALID, BI_KEEP_CKPT = 0, 1, 2, 4, 16, 32, 64
+REV_R, REV_K, REV_V, REV_W, REV_Y, REV_ALL = 1, 2, 4, 8, 16, 31      # wkv6_*_rev_ex: tensors held in reversed order
 
 ERRORS = {-1: "WKV6_EINVAL (shape: need C == H*64 and B,T,C,H >= 1)", -2: "WKV6_ENULL (null pointer)",
           -3: "WKV6_EWORKSPACE (workspace too small / allocation failed)", -4: "WKV6_EUNSUPPORTED"}

@@ -80,23 +80,26 @@ class Tmix_x060(nn.Module):
             return x.is_cuda and x.dtype == torch.bfloat16
         return self.fused
 
-    def jit_func(self, x, shifted=None):
+    def jit_func(self, x, shifted=None, rev_n=None):
         """Inputs of the WKV operator from the block input (src/model.py:435-459): every projection reads its own
         data-dependent blend of x_t and x_{t-1},  x + (x_{t-1} - x) * (maa_s + m_s),  where the five corrections m_s come
         from one shared low-rank pair (tanh(blend_x @ W1) -> per-stream W2).  Then r, k, v = Linear(blend), g = silu(Linear),
         w = time_decay + tanh(blend_w @ D1) @ D2.
         `shifted`: x delayed by one token; default zero-padded (nn.ZeroPad2d((0,0,1,-1))), the infctx path passes the
         previous chunk's last token in front (src/model.py:740-741).
-        On bf16 GPU tensors the two blend stages are one HIP kernel each (mix_op.ddlerp)."""
+        On bf16 GPU tensors the two blend stages are one HIP kernel each (mix_op.ddlerp).
+        `rev_n` (fused path only, int32 [B]): the token shift runs over the stream whose first rev_n[b] tokens are reversed
+        while every tensor stays in the original token order (row n2)."""
         B, T, C = x.size()
         if self._use_fused(x):
             from . import mix_op
             first = None if shifted is None else shifted[:, 0].contiguous()
-            lead = mix_op.ddlerp(x, self.time_maa_x.view(1, C), None, first)[0]
+            lead = mix_op.ddlerp(x, self.time_maa_x.view(1, C), None, first, rev_n)[0]
             low = torch.tanh(lead @ self.time_maa_w1).view(B * T, 5, -1).transpose(0, 1)
             corr = torch.bmm(low, self.time_maa_w2).view(5, B, T, C)
-            xw, xk, xv, xr, xg = mix_op.ddlerp(x, self._maa5(), corr, first).unbind(0)
+            xw, xk, xv, xr, xg = mix_op.ddlerp(x, self._maa5(), corr, first, rev_n).unbind(0)
         else:
+            assert rev_n is None, "the reversed-stream shift exists in the fused (HIP) path only"
             prev = F.pad(x, (0, 0, 1, -1)) if shifted is None else shifted
             delta = prev - x
             lead = torch.addcmul(x, delta, self.time_maa_x)
@@ -126,12 +129,30 @@ class Tmix_x060(nn.Module):
         r, k, v, g, w = self.jit_func(x)
         return self.jit_func_2(self._run(r, k, v, w), g)
 
+    def _rev_wkv(self, r, k, v, w, rev_n, rev_mask):
+        from .wkv import WKV_6_REV
+        B, T, C = r.shape
+        bf = torch.bfloat16
+        return WKV_6_REV.apply(B, T, C, self.n_head, *(t.to(bf).contiguous() for t in (r, k, v, w, self.time_faaaa)),
+                               rev_n, rev_mask).to(r.dtype)
+
+    def _in_kernel_reversal(self, x):
+        """Rows n2: with the HIP operator on bf16 GPU tensors the reversed half of the bidirectional compositions is
+        addressed inside the kernels (wkv6_*_rev_ex, ddlerp rev_n) instead of through torch.gather round trips."""
+        return self.wkv is _default_wkv and self._use_fused(x)
+
     def forward_bi_c(self, x, rev_idx, mask=None):
         """composition C (src/model_ext.py:421-437): reverse the hidden states, project twice, average."""
         r, k, v, g, w = self.jit_func(x)
-        rr, rk, rv, _, rw = self.jit_func(reverse_x(x, rev_idx))
         y = self._run(r, k, v, w)
-        ry = reverse_x(self._run(rr, rk, rv, rw), rev_idx)
+        if mask is not None and self._in_kernel_reversal(x):
+            from .wkv6_op import REV_ALL
+            rev_n = mask.sum(dim=1).to(torch.int32)
+            rr, rk, rv, _, rw = self.jit_func(x, rev_n=rev_n)      # the reversed stream's projections, in original order
+            ry = self._rev_wkv(rr, rk, rv, rw, rev_n, REV_ALL)
+        else:
+            rr, rk, rv, _, rw = self.jit_func(reverse_x(x, rev_idx))
+            ry = reverse_x(self._run(rr, rk, rv, rw), rev_idx)
         return self.jit_func_2((y + ry) / 2, g)
 
     def forward_bi_b(self, x, mask=None):
@@ -139,9 +160,13 @@ class Tmix_x060(nn.Module):
         B, T, C = x.size()
         if mask is None:
             mask = torch.ones(B, T, device=x.device)
-        rev_idx = reverse_x_idx(mask, T)
         r, k, v, g, w = self.jit_func(x)
         y = self._run(r, k, v, w)
+        if self._in_kernel_reversal(x):
+            from .wkv6_op import REV_K, REV_V, REV_Y
+            ry = self._rev_wkv(r, k, v, w, mask.sum(dim=1).to(torch.int32), REV_K | REV_V | REV_Y)
+            return self.jit_func_2(y + ry, g)
+        rev_idx = reverse_x_idx(mask, T)
         ry = self._run(r, reverse_x(k, rev_idx), reverse_x(v, rev_idx), w)
         return self.jit_func_2(y + reverse_x(ry, rev_idx), g)
 

@@ -194,6 +194,44 @@ int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, c
     return to_rc(run_bwd(a, flags, reinterpret_cast<float*>(workspace), (hipStream_t)stream));
 }
 
+int wkv6_forward_rev_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v, const void* w,
+                        const void* u, void* y, void* ckpt, size_t ckpt_bytes, const int* rev_n, unsigned rev_mask,
+                        unsigned flags, void* stream)
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!r || !k || !v || !w || !u || !y || !rev_n) return WKV6_ENULL;
+    if ((flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) || (rev_mask & ~(unsigned)REV_ALL)) return WKV6_EUNSUPPORTED;
+    if (ckpt && ckpt_bytes < wkv6_backward_workspace_bytes(B, T, C, H)) return WKV6_EWORKSPACE;
+    ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
+    a.y = y;
+    a.ckpt = reinterpret_cast<float*>(ckpt);
+    a.rev_n = rev_n;
+    a.rev_mask = rev_mask;
+    return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
+}
+
+int wkv6_backward_rev_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v, const void* w,
+                         const void* u, const void* gy, void* gr, void* gk, void* gv, void* gw, void* gu,
+                         void* workspace, size_t workspace_bytes, const int* rev_n, unsigned rev_mask, unsigned flags,
+                         void* stream)
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw || !rev_n) return WKV6_ENULL;
+    if ((flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) || (rev_mask & ~(unsigned)REV_ALL)) return WKV6_EUNSUPPORTED;
+    const size_t need = wkv6_backward_workspace_bytes(B, T, C, H);
+    if (!workspace) {
+        workspace = internal_scratch(need);
+        if (!workspace) return WKV6_EWORKSPACE;
+    } else if (workspace_bytes < need) {
+        return WKV6_EWORKSPACE;
+    }
+    ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
+    a.gy = gy; a.gr = gr; a.gk = gk; a.gv = gv; a.gw = gw; a.gu = gu;
+    a.rev_n = rev_n;
+    a.rev_mask = rev_mask;
+    return to_rc(run_bwd(a, flags, reinterpret_cast<float*>(workspace), (hipStream_t)stream));
+}
+
 int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
                       const void* k, const void* v, const void* w, const void* u, void* y,
                       void* workspace, size_t workspace_bytes, unsigned flags, void* stream)

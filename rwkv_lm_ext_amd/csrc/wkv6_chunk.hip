@@ -62,6 +62,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const int ngrp = (ntok + GRP - 1) / GRP;
+    const RevMap tokmap = make_revmap(a, b, ntok);
 
     if (producer) {
         // ================================ producer: operands of block wv =================================
@@ -77,13 +78,13 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 pr[tt] = pk[tt] = pv[tt] = pw[tt] = make_uint2(0u, 0u);
                 pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p < ntok) {
-                    const int t = a.reverse ? ntok - 1 - p : p;
-                    const unsigned idx = (unsigned)(t * a.C + 4 * c4);
-                    if constexpr (!STATE_ONLY) pr[tt] = *reinterpret_cast<const uint2*>(gr_ + idx);
-                    pk[tt] = *reinterpret_cast<const uint2*>(gk_ + idx);
-                    pv[tt] = *reinterpret_cast<const uint2*>(gv_ + idx);
-                    if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + base + idx);
-                    else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + base + idx);
+                    const unsigned ir = (unsigned)(tokmap(p, REV_R) * a.C + 4 * c4), ik = (unsigned)(tokmap(p, REV_K) * a.C + 4 * c4);
+                    const unsigned iv = (unsigned)(tokmap(p, REV_V) * a.C + 4 * c4), iw = (unsigned)(tokmap(p, REV_W) * a.C + 4 * c4);
+                    if constexpr (!STATE_ONLY) pr[tt] = *reinterpret_cast<const uint2*>(gr_ + ir);
+                    pk[tt] = *reinterpret_cast<const uint2*>(gk_ + ik);
+                    pv[tt] = *reinterpret_cast<const uint2*>(gv_ + iv);
+                    if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + base + iw);
+                    else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + base + iw);
                 }
             }
         };
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                         const int p = grp * GRP + blk * BLK + x;
                         const bool valid = p < ntok;
                         const int pc = valid ? p : 0;                    // padding lanes still form a legal address
-                        const int t = a.reverse ? ntok - 1 - pc : pc;
+                        const int t = tokmap(pc, REV_Y);
                         const unsigned idx = (unsigned)(t * a.C + 16 * wv + 4 * g);
                         float o[4] = {yt[0] + yi[0], yt[1] + yi[1], yt[2] + yi[2], yt[3] + yi[3]};
                         if constexpr (ACC) {

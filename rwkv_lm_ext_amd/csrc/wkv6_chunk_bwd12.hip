@@ -90,6 +90,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw) + base;
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
+    const RevMap tokmap = make_revmap(a, b, ntok);
     // gradient store: plain; or (wkv6_bi) first half into the fp32 side buffer, second half adds it and rounds once
     auto emit = [&](int which, bf16_t* out, unsigned idx, float (&o)[4]) {
         float* const side = a.g_f32[which];
@@ -125,14 +126,15 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             pr[tt] = pk[tt] = pv[tt] = pg[tt] = pw[tt] = make_uint2(0u, 0u);
             pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < ntok) {
-                const int t = a.reverse ? ntok - 1 - p : p;
-                const unsigned idx = (unsigned)(t * a.C + ch0);
-                pr[tt] = *reinterpret_cast<const uint2*>(gr_ + idx);
-                pk[tt] = *reinterpret_cast<const uint2*>(gk_ + idx);
-                pv[tt] = *reinterpret_cast<const uint2*>(gv_ + idx);
-                pg[tt] = *reinterpret_cast<const uint2*>(ggy + idx);
-                if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + base + idx);
-                else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + base + idx);
+                const unsigned ir = (unsigned)(tokmap(p, REV_R) * a.C + ch0), ik = (unsigned)(tokmap(p, REV_K) * a.C + ch0);
+                const unsigned iv = (unsigned)(tokmap(p, REV_V) * a.C + ch0), iw = (unsigned)(tokmap(p, REV_W) * a.C + ch0);
+                const unsigned ig = (unsigned)(tokmap(p, REV_Y) * a.C + ch0);
+                pr[tt] = *reinterpret_cast<const uint2*>(gr_ + ir);
+                pk[tt] = *reinterpret_cast<const uint2*>(gk_ + ik);
+                pv[tt] = *reinterpret_cast<const uint2*>(gv_ + iv);
+                pg[tt] = *reinterpret_cast<const uint2*>(ggy + ig);
+                if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + base + iw);
+                else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + base + iw);
             }
         }
     };
@@ -456,11 +458,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                         at[blk][q] = rv[q] * dq;
                     }
                     const int p = grp * STG + blk * BLK + x;
-                    if (p < ntok) {
-                        const int t = a.reverse ? ntok - 1 - p : p;
-                        const unsigned idx = (unsigned)(t * a.C + ch);
-                        emit(0, ogr, idx, o_gr);
-                    }
+                    if (p < ntok) emit(0, ogr, (unsigned)(tokmap(p, REV_R) * a.C + ch), o_gr);
                 }
             }
             WKV6_T(ts3);
@@ -529,10 +527,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                     }
                     const int p = grp * STG + blk * BLK + x;
                     if (p < ntok) {
-                        const int t = a.reverse ? ntok - 1 - p : p;
-                        const unsigned idx = (unsigned)(t * a.C + ch);
-                        emit(1, ogk, idx, o_gk);
-                        emit(3, ogw, idx, o_gw);
+                        emit(1, ogk, (unsigned)(tokmap(p, REV_K) * a.C + ch), o_gk);
+                        emit(3, ogw, (unsigned)(tokmap(p, REV_W) * a.C + ch), o_gw);
                     }
                 }
                 // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
@@ -647,10 +643,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                 {
                     const int p = grp * STG + blk * BLK + x;
                     if (p < ntok) {
-                        const int t = a.reverse ? ntok - 1 - p : p;
-                        const unsigned idx = (unsigned)(t * a.C + 16 * wv + 4 * g);
                         float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-                        emit(2, ogv, idx, o);
+                        emit(2, ogv, (unsigned)(tokmap(p, REV_V) * a.C + 16 * wv + 4 * g), o);
                     }
                 }
                 // ---- G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)

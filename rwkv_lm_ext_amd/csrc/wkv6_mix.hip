@@ -22,6 +22,7 @@ struct LerpArgs {
     int B, T, C, NS;
     const bf16_t* x;          // [B,T,C]
     const bf16_t* shifted0;   // [B,C] token in front of every row (infctx), or null (zero)
+    const int* rev_n;         // [B] or null: the shift runs over the stream "first rev_n[b] tokens reversed, rest in place"
     const bf16_t* m;          // [NS,B,T,C] or null
     const bf16_t* maa;        // [NS,C]
     bf16_t* out;              // [NS,B,T,C]
@@ -35,6 +36,23 @@ struct LerpArgs {
 
 __device__ __forceinline__ void ld4(const bf16_t* p, float (&o)[4]) { io4<bf16_t>::load(p, o); }
 
+// Token shift over a partially reversed stream, in the ORIGINAL token order: the bidirectional encoder
+// reverses the first n tokens of a row (reverse_x_idx, src/model_ext.py:410-417), runs the time-mix on that stream and
+// un-reverses the result.  Stream position of token t: n-1-t for t < n, t otherwise.  prev_tok = the token one stream
+// position earlier (-1: the row's leading pad), next_tok = the token one stream position later (-1: none); n = 0: plain.
+__device__ __forceinline__ int prev_tok(int t, int n)
+{
+    if (n <= 0 || t > n) return t - 1;
+    if (t < n - 1) return t + 1;
+    return t == n ? 0 : -1;                              // t == n: behind the reversed span sits token 0; t == n-1: stream start
+}
+__device__ __forceinline__ int next_tok(int t, int n, int T)
+{
+    if (n <= 0 || t >= n) return t + 1 < T ? t + 1 : -1;
+    if (t >= 1) return t - 1;
+    return n < T ? n : -1;                               // token 0 closes the reversed span
+}
+
 template <int NS, bool HAS_M>
 __global__ void ddlerp_fwd_kernel(const LerpArgs a)
 {
@@ -43,7 +61,9 @@ __global__ void ddlerp_fwd_kernel(const LerpArgs a)
     const int c = 4 * threadIdx.x;
     float x[4], xp[4] = {0.f, 0.f, 0.f, 0.f};
     ld4(a.x + row * a.C + c, x);
-    if (t > 0) ld4(a.x + (row - 1) * a.C + c, xp);
+    const int nrev = a.rev_n ? min(max(a.rev_n[b], 0), a.T) : 0;
+    const int tp = prev_tok(t, nrev);
+    if (tp >= 0) ld4(a.x + ((long)b * a.T + tp) * a.C + c, xp);
     else if (a.shifted0) ld4(a.shifted0 + (long)b * a.C + c, xp);
     const long plane = (long)a.B * a.T * a.C;
 #pragma unroll
@@ -75,9 +95,12 @@ __global__ void ddlerp_bwd_kernel(const LerpArgs a)
         const int t = (int)(row % a.T), b = (int)(row / a.T);
         float x[4], xp[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
         ld4(a.x + row * a.C + c, x);
-        if (t > 0) ld4(a.x + (row - 1) * a.C + c, xp);
+        const int nrev = a.rev_n ? min(max(a.rev_n[b], 0), a.T) : 0;
+        const int tp = prev_tok(t, nrev), tn = next_tok(t, nrev, a.T);
+        if (tp >= 0) ld4(a.x + ((long)b * a.T + tp) * a.C + c, xp);
         else if (a.shifted0) ld4(a.shifted0 + (long)b * a.C + c, xp);
-        const bool has_next = t + 1 < a.T;
+        const bool has_next = tn >= 0;
+        const long rown = (long)b * a.T + tn;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             float d[4], m[4] = {0.f, 0.f, 0.f, 0.f};
@@ -94,8 +117,8 @@ __global__ void ddlerp_bwd_kernel(const LerpArgs a)
             if constexpr (HAS_M) io4<bf16_t>::store(a.dm + s * plane + row * a.C + c, dm);
             if (has_next) {
                 float dn[4], mn[4] = {0.f, 0.f, 0.f, 0.f};
-                ld4(a.dout + s * plane + (row + 1) * a.C + c, dn);
-                if constexpr (HAS_M) ld4(a.m + s * plane + (row + 1) * a.C + c, mn);
+                ld4(a.dout + s * plane + rown * a.C + c, dn);
+                if constexpr (HAS_M) ld4(a.m + s * plane + rown * a.C + c, mn);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) g[q] = fmaf(dn[q], maa[s][q] + mn[q], g[q]);
             }
@@ -212,8 +235,8 @@ using namespace wkv6;
 
 extern "C" {
 
-int wkv6_ddlerp_forward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
-                        void* out, void* stream)
+int wkv6_ddlerp_rev_forward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
+                            const int* rev_n, void* out, void* stream)
 {
     if (B < 1 || T < 1) return WKV6_EINVAL;
     if (int rc = check_rows((long)B * T, C)) return rc;
@@ -221,12 +244,23 @@ int wkv6_ddlerp_forward(int B, int T, int C, int NS, const void* x, const void* 
     LerpArgs a = {};
     a.B = B; a.T = T; a.C = C; a.NS = NS;
     a.x = (const bf16_t*)x; a.shifted0 = (const bf16_t*)shifted0; a.m = (const bf16_t*)m; a.maa = (const bf16_t*)maa;
+    a.rev_n = rev_n;
     a.out = (bf16_t*)out;
     return dispatch_lerp(a, false, (hipStream_t)stream);
+}
+int wkv6_ddlerp_forward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
+                        void* out, void* stream)
+{
+    return wkv6_ddlerp_rev_forward(B, T, C, NS, x, shifted0, m, maa, nullptr, out, stream);
 }
 
 int wkv6_ddlerp_backward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
                          const void* dout, void* dx, void* dm, float* dmaa_part, int nparts, void* stream)
+{
+    return wkv6_ddlerp_rev_backward(B, T, C, NS, x, shifted0, m, maa, nullptr, dout, dx, dm, dmaa_part, nparts, stream);
+}
+int wkv6_ddlerp_rev_backward(int B, int T, int C, int NS, const void* x, const void* shifted0, const void* m, const void* maa,
+                             const int* rev_n, const void* dout, void* dx, void* dm, float* dmaa_part, int nparts, void* stream)
 {
     if (B < 1 || T < 1 || nparts < 1) return WKV6_EINVAL;
     if (int rc = check_rows((long)B * T, C)) return rc;
@@ -234,6 +268,7 @@ int wkv6_ddlerp_backward(int B, int T, int C, int NS, const void* x, const void*
     LerpArgs a = {};
     a.B = B; a.T = T; a.C = C; a.NS = NS;
     a.x = (const bf16_t*)x; a.shifted0 = (const bf16_t*)shifted0; a.m = (const bf16_t*)m; a.maa = (const bf16_t*)maa;
+    a.rev_n = rev_n;
     a.dout = (const bf16_t*)dout; a.dx = (bf16_t*)dx; a.dm = (bf16_t*)dm; a.dmaa_part = dmaa_part; a.nparts = nparts;
     return dispatch_lerp(a, true, (hipStream_t)stream);
 }

@@ -66,10 +66,28 @@ struct ScanArgs {
     int ckpt_valid;                   // backward: ckpt was filled by the forward, skip the state pass
     const int* lens;                  // per-batch number of tokens to scan (null: T)
     int reverse;                      // 1: scan tokens lens-1 .. 0
+    const int* rev_n;                 // chunked kernels: per-batch number of leading tokens that the tensors named in rev_mask
+    unsigned rev_mask;                //   hold in reverse order (scan position p < rev_n[b] <-> token rev_n[b]-1-p; positions
+                                      //   beyond keep their place); every token is still scanned.  Bits: REV_*
     int use_u;                        // 0: bonus u treated as 0 (reverse half of wkv6_bi)
     int accumulate;                   // 1: add into y / gr,gk,gv,gw instead of overwriting
     int zero_tail;                    // 1: write zeros for tokens >= lens[b]
 };
+
+enum { REV_R = 1, REV_K = 2, REV_V = 4, REV_W = 8, REV_Y = 16, REV_ALL = 31 };   // REV_Y: y in the forward, gy in the backward;
+                                                                                // every gradient follows its tensor's bit
+// token a tensor holds at scan position p
+struct RevMap {
+    int n;
+    unsigned mask;
+    __device__ __forceinline__ int operator()(int p, unsigned bit) const { return ((mask & bit) && p < n) ? n - 1 - p : p; }
+};
+__device__ __forceinline__ RevMap make_revmap(const ScanArgs& a, int b, int ntok)
+{
+    if (a.reverse) return RevMap{ntok, REV_ALL};
+    if (a.rev_n) return RevMap{min(max(a.rev_n[b], 0), ntok), a.rev_mask};
+    return RevMap{0, 0u};
+}
 
 hipError_t launch_scan_fwd(const ScanArgs& a, bool io_f32, hipStream_t st);
 hipError_t launch_scan_bwd(const ScanArgs& a, bool io_f32, hipStream_t st);

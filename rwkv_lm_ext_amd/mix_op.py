@@ -19,26 +19,30 @@ def _require(t, name):
 
 
 class _DDLerp(torch.autograd.Function):
-    """out[s] = x + (shift(x) - x) * (maa[s] + m[s]);  x [B,T,C], maa [NS,C], m [NS,B,T,C] or None -> out [NS,B,T,C]."""
+    """out[s] = x + (shift(x) - x) * (maa[s] + m[s]);  x [B,T,C], maa [NS,C], m [NS,B,T,C] or None -> out [NS,B,T,C].
+    rev_n (int32 [B] or None): the shift runs over the stream whose first rev_n[b] tokens are reversed."""
 
     @staticmethod
-    def forward(ctx, x, maa, m, shifted0):
+    def forward(ctx, x, maa, m, shifted0, rev_n):
         x, maa = _require(x, "x"), _require(maa, "maa")
         m = None if m is None else _require(m, "m")
         shifted0 = None if shifted0 is None else _require(shifted0, "shifted0")
         B, T, C = x.shape
+        if rev_n is not None and not (rev_n.dtype == torch.int32 and rev_n.is_contiguous() and tuple(rev_n.shape) == (B,)
+                                      and rev_n.device == x.device):
+            raise RuntimeError("rev_n must be a contiguous int32 [B] tensor on the device of x")
         NS = maa.shape[0]
         out = torch.empty((NS, B, T, C), device=x.device, dtype=x.dtype)
         with torch.cuda.device(x.device):
-            rc = _lib.load().wkv6_ddlerp_forward(B, T, C, NS, _ptr(x), _ptr(shifted0), _ptr(m), _ptr(maa), _ptr(out),
-                                                 _stream_ptr())
+            rc = _lib.load().wkv6_ddlerp_rev_forward(B, T, C, NS, _ptr(x), _ptr(shifted0), _ptr(m), _ptr(maa), _ptr(rev_n),
+                                                     _ptr(out), _stream_ptr())
         _lib.check(rc, "ddlerp forward")
-        ctx.save_for_backward(x, maa, m, shifted0)
+        ctx.save_for_backward(x, maa, m, shifted0, rev_n)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, maa, m, shifted0 = ctx.saved_tensors
+        x, maa, m, shifted0, rev_n = ctx.saved_tensors
         dout = _require(dout, "dout")
         B, T, C = x.shape
         NS = maa.shape[0]
@@ -47,15 +51,15 @@ class _DDLerp(torch.autograd.Function):
         dm = None if m is None else torch.empty_like(m)
         part = torch.empty((nparts, NS, C), device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
-            rc = _lib.load().wkv6_ddlerp_backward(B, T, C, NS, _ptr(x), _ptr(shifted0), _ptr(m), _ptr(maa), _ptr(dout),
-                                                  _ptr(dx), _ptr(dm), _ptr(part), nparts, _stream_ptr())
+            rc = _lib.load().wkv6_ddlerp_rev_backward(B, T, C, NS, _ptr(x), _ptr(shifted0), _ptr(m), _ptr(maa), _ptr(rev_n),
+                                                      _ptr(dout), _ptr(dx), _ptr(dm), _ptr(part), nparts, _stream_ptr())
         _lib.check(rc, "ddlerp backward")
-        return dx, part.sum(0).to(maa.dtype), dm, None      # the token in front of the row (infctx carry) gets no gradient
+        return dx, part.sum(0).to(maa.dtype), dm, None, None   # the token in front of the row (infctx carry) gets no gradient
 
 
-def ddlerp(x, maa, m=None, shifted0=None):
+def ddlerp(x, maa, m=None, shifted0=None, rev_n=None):
     """maa: [NS,C] (or anything reshapeable to it, e.g. five [1,1,C] parameters stacked)."""
-    return _DDLerp.apply(x, maa.reshape(-1, x.shape[-1]), m, shifted0)
+    return _DDLerp.apply(x, maa.reshape(-1, x.shape[-1]), m, shifted0, rev_n)
 
 
 class _GroupNormGate(torch.autograd.Function):

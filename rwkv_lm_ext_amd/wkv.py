@@ -62,6 +62,32 @@ class WKV_6(torch.autograd.Function):
             return (None, None, None, None, gr, gk, gv, gw, gu)
 
 
+class WKV_6_REV(torch.autograd.Function):
+    """WKV_6 on partially reversed sequences: what the reference writes as
+    `reverse_x(WKV_6.apply(.., reverse_x(k, idx), reverse_x(v, idx), ..), idx)` (src/model_bi.py:331-348, rev_mask =
+    REV_K | REV_V | REV_Y) or with every tensor reversed (src/model_ext.py:421-437, REV_ALL), without the gathers:
+    `rev_n[b]` = number of leading tokens of row b that are reversed (= mask.sum(1), src/model_ext.py:410-417)."""
+
+    @staticmethod
+    def forward(ctx, B, T, C, H, r, k, v, w, u, rev_n, rev_mask):
+        with torch.no_grad():
+            _assert_inputs(C, H, r, k, v, w, u)
+            ctx.H, ctx.C, ctx.rev_mask = H, C, rev_mask
+            ctx.save_for_backward(r, k, v, w, u, rev_n)
+            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
+            return wkv6_op.forward_rev_ex(r, k, v, w, u, H, rev_n, rev_mask, ckpt=ctx.ckpt)
+
+    @staticmethod
+    def backward(ctx, gy):
+        with torch.no_grad():
+            assert gy.dtype == torch.bfloat16
+            r, k, v, w, u, rev_n = ctx.saved_tensors
+            gr, gk, gv, gw, gu = wkv6_op.backward_rev_ex(r, k, v, w, u, gy.contiguous(), ctx.H, rev_n, ctx.rev_mask,
+                                                          ckpt=ctx.ckpt)
+            ctx.ckpt = None
+            return (None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (ctx.H, ctx.C // ctx.H)), None, None)
+
+
 def RUN_CUDA_RWKV6(B, T, C, H, r, k, v, w, u):
     return WKV_6.apply(B, T, C, H, r, k, v, w, u)
 

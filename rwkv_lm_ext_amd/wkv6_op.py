@@ -273,6 +273,59 @@ def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False, alg
     return gr, gk, gv, gw, gu, gs
 
 
+REV_R, REV_K, REV_V, REV_W, REV_Y, REV_ALL = _lib.REV_R, _lib.REV_K, _lib.REV_V, _lib.REV_W, _lib.REV_Y, _lib.REV_ALL
+
+
+def _check_rev(B, rev_n, rev_mask, dev):
+    if not (isinstance(rev_n, torch.Tensor) and rev_n.dtype == torch.int32 and rev_n.is_contiguous() and
+            tuple(rev_n.shape) == (B,) and rev_n.device == dev):
+        raise RuntimeError("rev_n must be a contiguous int32 [B] tensor on the device of r")
+    if rev_mask & ~REV_ALL:
+        raise RuntimeError(f"rev_mask {rev_mask} has unknown bits")
+
+
+def forward_rev_ex(r, k, v, w, u, H, rev_n, rev_mask, y=None, ckpt=None):
+    """WKV6 over partially reversed sequences without materialising the reversal (include/wkv6_amd.h, wkv6_forward_rev_ex):
+    tokens [0, rev_n[b]) of the tensors named in `rev_mask` (REV_R | REV_K | REV_V | REV_W | REV_Y) are taken in reverse
+    order, the rest in place; bf16 only."""
+    B, T, C = r.shape
+    btc, io = (B, T, C), torch.bfloat16
+    if y is None:
+        y = torch.empty(btc, device=r.device, dtype=io)
+    named = dict(r=(r, btc, io), k=(k, btc, io), v=(v, btc, io), w=(w, btc, io), u=(u, (H, HEAD_SIZE), io), y=(y, btc, io))
+    dev = _check_tensors(B, T, C, H, named, dtype=io)
+    _check_rev(B, rev_n, rev_mask, dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().wkv6_forward_rev_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(y), _ptr(ckpt),
+                                             0 if ckpt is None else ckpt.numel(), _ptr(rev_n), rev_mask, _lib.W_RAW,
+                                             _stream_ptr())
+    _lib.check(rc, "wkv6 forward_rev_ex")
+    return y
+
+
+def backward_rev_ex(r, k, v, w, u, gy, H, rev_n, rev_mask, ckpt=None):
+    """Gradients of forward_rev_ex: (gr, gk, gv, gw, gu[B,C]); each gradient is laid out like its tensor."""
+    B, T, C = r.shape
+    btc, io = (B, T, C), torch.bfloat16
+    named = dict(r=(r, btc, io), k=(k, btc, io), v=(v, btc, io), w=(w, btc, io), u=(u, (H, HEAD_SIZE), io), gy=(gy, btc, io))
+    dev = _check_tensors(B, T, C, H, named, dtype=io)
+    _check_rev(B, rev_n, rev_mask, dev)
+    gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
+    gu = torch.empty((B, C), device=dev, dtype=io)
+    flags = _lib.W_RAW
+    if ckpt is not None:
+        ws = ckpt
+        flags |= _lib.CKPT_VALID
+    else:
+        ws = torch.empty(_lib.load().wkv6_backward_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().wkv6_backward_rev_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(gy), _ptr(gr),
+                                              _ptr(gk), _ptr(gv), _ptr(gw), _ptr(gu), _ptr(ws), ws.numel(), _ptr(rev_n),
+                                              rev_mask, flags, _stream_ptr())
+    _lib.check(rc, "wkv6 backward_rev_ex")
+    return gr, gk, gv, gw, gu
+
+
 def bi_new_workspace(B, T, C, H, device):
     """Workspace of the wkv6_bi pair: the forward's fp32 y side buffer, the state checkpoints of both scans (kept from
     forward to backward when `ws` is passed to both calls) and the backward's four fp32 gradient side buffers."""
