@@ -34,6 +34,14 @@ def _assert_inputs(C, H, *tensors):
     assert HEAD_SIZE == C // H
 
 
+def _keep_ckpt(ctx):
+    """Let the forward store its fp32 state checkpoints (8 B per token-channel, e.g. 537 MB per layer at B=8, T=4096, C=2048)
+    for the backward?  Only when a backward will follow, and not with RWKV_AMD_NO_CKPT=1: then nothing is kept between the two
+    calls and the backward rebuilds the checkpoints with a state pass (+≈0.23 ms at that shape) -- the choice when activation
+    memory matters more than time."""
+    return any(ctx.needs_input_grad) and os.environ.get("RWKV_AMD_NO_CKPT", "0") != "1"
+
+
 def _sum_bf16(partials, shape):
     return partials.float().sum(0).to(torch.bfloat16).view(shape)
 
@@ -47,7 +55,7 @@ class WKV_6(torch.autograd.Function):
             ctx.save_for_backward(r, k, v, w, u)
             # when a backward will follow, let the forward store its per-32-token state checkpoints (fp32, 8 B per
             # token-channel) so the backward does not have to recompute them with a state pass
-            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
+            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if _keep_ckpt(ctx) else None
             return wkv6_op.forward_ex(r, k, v, w, u, H, ckpt=ctx.ckpt)
 
     @staticmethod
@@ -74,7 +82,7 @@ class WKV_6_REV(torch.autograd.Function):
             _assert_inputs(C, H, r, k, v, w, u)
             ctx.H, ctx.C, ctx.rev_mask = H, C, rev_mask
             ctx.save_for_backward(r, k, v, w, u, rev_n)
-            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
+            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if _keep_ckpt(ctx) else None
             return wkv6_op.forward_rev_ex(r, k, v, w, u, H, rev_n, rev_mask, ckpt=ctx.ckpt)
 
     @staticmethod
@@ -101,7 +109,7 @@ class WKV_6STATE(torch.autograd.Function):
             _assert_inputs(C, H, r, k, v, w, u, s)
             ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
             ctx.save_for_backward(r, k, v, w, u, s)
-            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
+            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if _keep_ckpt(ctx) else None
             return wkv6_op.forward_ex(r, k, v, w, u, H, s0=s, ckpt=ctx.ckpt)
 
     @staticmethod
@@ -126,7 +134,7 @@ class WKV_6STATE_INFCTX(torch.autograd.Function):
             ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
             s_init = s.clone()
             ctx.save_for_backward(r, k, v, w, u, s_init)
-            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
+            ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if _keep_ckpt(ctx) else None
             # s <- final state, written through the raw pointer exactly like the reference kernel does
             return wkv6_op.forward_ex(r, k, v, w, u, H, s0=s_init, s_out=s, ckpt=ctx.ckpt)
 
@@ -166,7 +174,7 @@ class WKV_6_BI(torch.autograd.Function):
             ctx.mask = mask
             ctx.save_for_backward(r, k, v, w, u)
             # when a backward will follow, both scans leave their state checkpoints in the workspace
-            ctx.ws = wkv6_op.bi_new_workspace(B, T, C, H, r.device) if any(ctx.needs_input_grad) else None
+            ctx.ws = wkv6_op.bi_new_workspace(B, T, C, H, r.device) if _keep_ckpt(ctx) else None
             return wkv6_op.bi_forward_ex(mask, r, k, v, w, u, H, ws=ctx.ws)
 
     @staticmethod

@@ -240,6 +240,30 @@ def test_autograd_surface(ops, oracle):
     assert max_norm_err(host(leaves[1].grad), ob["gk"]) <= 8e-3
 
 
+def test_checkpoint_opt_out_gives_identical_gradients(ops, monkeypatch):
+    """RWKV_AMD_NO_CKPT=1: nothing is kept from forward to backward, the backward rebuilds the state checkpoints itself --
+    same kernels on the same numbers, so every gradient is bit-identical (WKV_6 and WKV_6_BI)."""
+    from rwkv_lm_ext_amd.wkv import RUN_CUDA_RWKV6, RUN_CUDA_RWKV6_BI
+    bf = torch.bfloat16
+    B, T, H = 2, 96, 2
+    C = H * 64
+    r, k, v, w, u, gy = rand_inputs(7, B, T, H)
+    mask = torch.ones(B, T, dtype=torch.int32)
+    mask[1, 50:] = 0
+    res = []
+    for no_ckpt in ("0", "1"):
+        monkeypatch.setenv("RWKV_AMD_NO_CKPT", no_ckpt)
+        out = []
+        for bi in (False, True):
+            leaves = [dev(x, bf).requires_grad_(True) for x in (r, k, v, w, u)]
+            y = RUN_CUDA_RWKV6_BI(B, T, C, H, mask.cuda(), *leaves) if bi else RUN_CUDA_RWKV6(B, T, C, H, *leaves)
+            y.backward(dev(gy, bf))
+            out += [y.detach()] + [t.grad for t in leaves]
+        res.append(out)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_full_size_properties(ops):
     """BASELINE config 2 (B=8,T=4096,C=2048,H=32), where the CPU oracle would take minutes: properties
     that do not depend on size.  (a) splitting the sequence and carrying the fp32 state reproduces the
