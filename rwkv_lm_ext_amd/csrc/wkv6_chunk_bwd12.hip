@@ -262,11 +262,13 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                          "v"(pv[1].x), "v"(pg[1].x), "v"(pw[1].x));      // wait for the loads here
 #endif
             WKV6_T(ts1);
+#ifndef WKV6_ABL_NOPROD                                            // timing-only ablation: the stage images are prepared once
             if (grp > 0) {
                 prep_group(grp - 1);
                 WKV6_T(ts2);
                 if (grp > 1) load_group(grp - 2);
             }
+#endif
             WKV6_T(ts3);
             __syncthreads();
             WKV6_T(ts4);
@@ -323,6 +325,9 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
+#ifdef WKV6_ABL_NOROW                                              // timing-only ablation: row waves only keep the barrier count
+            if (grp != ngrp - 1) { __syncthreads(); continue; }
+#endif
             WKV6_T(ts0);
             // stage-entry forward state: read back what this wave requested a stage ago, then request the next one.
             // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here.  It was issued a whole stage ago,
@@ -556,6 +561,9 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         for (int t = 0; t < 4; ++t) GJ[t] = f4v{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
+#ifdef WKV6_ABL_NOCOL                                              // timing-only ablation: column waves only keep the barrier count
+            if (grp != ngrp - 1) { __syncthreads(); continue; }
+#endif
             WKV6_T(ts0);
             const char* const buf = smem + (grp & 1) * BUF_BYTES;
             // ---- pre-phase: everything that does not depend on G, stage-major over the 4 blocks so that many
