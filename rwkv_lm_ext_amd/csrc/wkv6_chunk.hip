@@ -63,6 +63,9 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const int ngrp = (ntok + GRP - 1) / GRP;
     const RevMap tokmap = make_revmap(a, b, ntok);
+#ifdef WKV6_STAMP
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+#endif
 
     if (producer) {
         // ================================ producer: operands of block wv =================================
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 }
             }
         };
-        auto prep_group = [&](int grp, int buf) {
+        // `next`: group whose loads are requested as soon as the raw registers are consumed (WKV6_FWD_MIDLOAD experiment), -1: none
+        auto prep_group = [&](int grp, int buf, int next) {
             char* const bb = smem + buf * GRP_BYTES + wv * BLK_BYTES;
             float r[4][4], k[4][4], cs[4][4];
 #pragma unroll
@@ -122,6 +126,9 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 }
                 *reinterpret_cast<uint2*>(bb + A_V * ARR + (4 * tq + tt) * RSB + 8 * c4) = pv[tt];
             }
+#ifdef WKV6_FWD_MIDLOAD
+            if (next >= 0) load_group(next);
+#endif
             float pre[4], c8[4], c16[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -194,16 +201,30 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 
         if (ngrp > 0) {
             load_group(0);
-            prep_group(0, 0);
+            prep_group(0, 0, ngrp > 1 ? 1 : -1);
+#ifndef WKV6_FWD_MIDLOAD
             if (ngrp > 1) load_group(1);
+#endif
         }
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
+            WKV6_T(ts0);
+#ifdef WKV6_STAMP
+            asm volatile("" :: "v"(pr[0].x), "v"(pk[0].x), "v"(pv[0].x), "v"(pw[0].x), "v"(pr[3].x), "v"(pk[3].x), "v"(pv[3].x),
+                         "v"(pw[3].x));                                  // wait for the loads here
+#endif
+            WKV6_T(ts1);
             if (grp + 1 < ngrp) {
-                prep_group(grp + 1, (grp + 1) & 1);
+                prep_group(grp + 1, (grp + 1) & 1, grp + 2 < ngrp ? grp + 2 : -1);
+                WKV6_T(ts2);
+#ifndef WKV6_FWD_MIDLOAD
                 if (grp + 2 < ngrp) load_group(grp + 2);
+#endif
             }
+            WKV6_T(ts3);
             __syncthreads();
+            WKV6_T(ts4);
+            WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3);
         }
     } else {
         // ============================== consumer: value columns [16wv, 16wv+16) =========================
@@ -224,6 +245,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
+            WKV6_T(ts0);
 
             // Rolled (runtime trip count): a fully unrolled 4-block body is no faster.  -DWKV6_FWD_UNROLL builds the unrolled
             // body for tools/check_unrolled_fwd.sh (the wrong y that build once produced was the mixed-shape
@@ -312,7 +334,10 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                     St[it][3] = fmaf(d16.w, St[it][3], dm.w * o[3]);
                 }
             }
+            WKV6_T(ts1);
             __syncthreads();
+            WKV6_T(ts2);
+            WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1);
         }
         if (a.s_out) {
             const long so_ = ((long)b * a.H + h) * HEAD * HEAD + (long)(16 * wv + x) * HEAD + 8 * g;
@@ -324,6 +349,12 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             }
         }
     }
+#ifdef WKV6_STAMP
+    if (a.aux && lane == 0) {
+        unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)blockIdx.x * 16 + wid) * 8;
+        for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
+    }
+#endif
     if (!STATE_ONLY && !ACC && a.zero_tail) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += 32)
@@ -342,8 +373,14 @@ template <bool W_RAW, bool STATE_ONLY, bool ACC> hipError_t launch_fwd_variant(c
 
 }  // namespace
 
-hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st)
+hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
 {
+#ifdef WKV6_STAMP
+    ScanArgs a = a_;
+    a.aux = reinterpret_cast<float*>(g_stamp_buffer);
+#else
+    const ScanArgs& a = a_;
+#endif
     const bool raw = a.wkind == 1;          // 0: fp32 ew = -exp(w), 1: raw w in bf16, 2: fp32 decay exp(-exp(w))
     if (a.accumulate) return raw ? launch_fwd_variant<true, false, true>(a, st) : launch_fwd_variant<false, false, true>(a, st);
     return raw ? launch_fwd_variant<true, false, false>(a, st) : launch_fwd_variant<false, false, false>(a, st);

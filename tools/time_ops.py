@@ -59,6 +59,15 @@ if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wav
     lib.wkv6_set_debug_buffer.argtypes = [ctypes.c_void_p]
     lib.wkv6_set_debug_buffer.restype = None
     lib.wkv6_set_debug_buffer(buf.data_ptr())
+    fwd()
+    torch.cuda.synchronize()
+    d = buf.view(B * H, 16, 8).double().mean(0)
+    ng = (T + 63) // 64
+    print("forward, cycles per 64-token group and wave (avg over workgroups):")
+    print("  consumers 0-3 = [body, barrier]   producers 4-7 = [load wait, prep, load issue, barrier]")
+    for wv in range(8):
+        print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / ng):8.0f}" for k in range(4)))
+    buf.zero_()
     bwd()
     torch.cuda.synchronize()
     d = buf.view(B * H, 16, 8).double().mean(0)         # average over workgroups: [wave][phase]
