@@ -18,7 +18,8 @@ int check_shape(int B, int T, int C, int H)
 {
     if (B < 1 || T < 1 || C < 1 || H < 1) return WKV6_EINVAL;
     if ((long)H * HEAD != (long)C) return WKV6_EINVAL;      // reference: assert(H*_N_ == C)
-    if ((long)T * C >= (1L << 31)) return WKV6_EUNSUPPORTED; // one sequence must stay 32-bit addressable (per-lane offsets)
+    if (((long)T + 64) * C >= (1L << 31)) return WKV6_EUNSUPPORTED; // one sequence (rounded up to whole groups) must stay 32-bit
+                                                                  // addressable: per-lane byte offsets of bf16 tensors are 32-bit
     return WKV6_OK;
 }
 

@@ -74,21 +74,24 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 4 * c4, uu);
         uint2 pr[4], pk[4], pv[4], pw[4];
         float4 pe[4];
+        // buffer resources over this row's first ntok tokens: loads of tokens past the end return 0 without a branch
+        const unsigned span = ntok > 0 ? (unsigned)(ntok - 1) * a.C : 0u;     // elements up to the last token's head slice
+        const rsrc_t rs_r = make_rsrc(gr_, ntok > 0 ? span * 2 + 128 : 0), rs_k = make_rsrc(gk_, ntok > 0 ? span * 2 + 128 : 0);
+        const rsrc_t rs_v = make_rsrc(gv_, ntok > 0 ? span * 2 + 128 : 0);
+        const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, ntok > 0 ? span * 2 + 128 : 0)
+                                  : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? span * 4 + 256 : 0);
         auto load_group = [&](int grp) {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int p = grp * GRP + wv * BLK + 4 * tq + tt;
-                pr[tt] = pk[tt] = pv[tt] = pw[tt] = make_uint2(0u, 0u);
-                pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p < ntok) {
-                    const unsigned ir = (unsigned)(tokmap(p, REV_R) * a.C + 4 * c4), ik = (unsigned)(tokmap(p, REV_K) * a.C + 4 * c4);
-                    const unsigned iv = (unsigned)(tokmap(p, REV_V) * a.C + 4 * c4), iw = (unsigned)(tokmap(p, REV_W) * a.C + 4 * c4);
-                    if constexpr (!STATE_ONLY) pr[tt] = *reinterpret_cast<const uint2*>(gr_ + ir);
-                    pk[tt] = *reinterpret_cast<const uint2*>(gk_ + ik);
-                    pv[tt] = *reinterpret_cast<const uint2*>(gv_ + iv);
-                    if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + base + iw);
-                    else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + base + iw);
-                }
+                const unsigned ir = (unsigned)(tokmap(p, REV_R) * a.C + 4 * c4), ik = (unsigned)(tokmap(p, REV_K) * a.C + 4 * c4);
+                const unsigned iv = (unsigned)(tokmap(p, REV_V) * a.C + 4 * c4), iw = (unsigned)(tokmap(p, REV_W) * a.C + 4 * c4);
+                if constexpr (!STATE_ONLY) pr[tt] = buf_load8(rs_r, ir * 2);
+                else pr[tt] = make_uint2(0u, 0u);
+                pk[tt] = buf_load8(rs_k, ik * 2);
+                pv[tt] = buf_load8(rs_v, iv * 2);
+                if constexpr (W_RAW) pw[tt] = buf_load8(rs_w, iw * 2);
+                else pe[tt] = buf_load16f(rs_w, iw * 4);
             }
         };
         // `next`: group whose loads are requested as soon as the raw registers are consumed (WKV6_FWD_MIDLOAD experiment), -1: none
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         }
         int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read, natural columns (this wave's V tile)
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
+        const rsrc_t rs_y = make_rsrc(gy_, (!STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
             WKV6_T(ts0);
@@ -300,21 +304,25 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                     }
                     {   // store: lane holds y[token x][j = 16wv + 4g + q]
                         const int p = grp * GRP + blk * BLK + x;
-                        const bool valid = p < ntok;
-                        const int pc = valid ? p : 0;                    // padding lanes still form a legal address
-                        const int t = tokmap(pc, REV_Y);
-                        const unsigned idx = (unsigned)(t * a.C + 16 * wv + 4 * g);
                         float o[4] = {yt[0] + yi[0], yt[1] + yi[1], yt[2] + yi[2], yt[3] + yi[3]};
-                        if constexpr (ACC) {
-                            float old[4];
-                            if (a.y_f32) io4<float>::load(a.y_f32 + base + idx, old);
-                            else io4<bf16_t>::load(gy_ + idx, old);
+                        if (!ACC && !a.y_f32) {                          // plain store: tokens past the end are dropped by the hardware
+                            buf_store8(rs_y, (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g) * 2u,
+                                       make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
+                        } else {
+                            const bool valid = p < ntok;
+                            const int pc = valid ? p : 0;                // padding lanes still form a legal address
+                            const unsigned idx = (unsigned)(tokmap(pc, REV_Y) * a.C + 16 * wv + 4 * g);
+                            if constexpr (ACC) {
+                                float old[4];
+                                if (a.y_f32) io4<float>::load(a.y_f32 + base + idx, old);
+                                else io4<bf16_t>::load(gy_ + idx, old);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) o[q] += old[q];
-                        }
-                        if (valid) {
-                            if (!ACC && a.y_f32) io4<float>::store(a.y_f32 + base + idx, o);
-                            else io4<bf16_t>::store(gy_ + idx, o);
+                                for (int q = 0; q < 4; ++q) o[q] += old[q];
+                            }
+                            if (valid) {
+                                if (!ACC && a.y_f32) io4<float>::store(a.y_f32 + base + idx, o);
+                                else io4<bf16_t>::store(gy_ + idx, o);
+                            }
                         }
                     }
                 }
@@ -373,8 +381,12 @@ template <bool W_RAW, bool STATE_ONLY, bool ACC> hipError_t launch_fwd_variant(c
 
 }  // namespace
 
+// per-lane byte offsets are 32-bit: bf16 tensors need (T + 64) C < 2^31 (checked by the API), the fp32 decay input half of that
+static bool offsets_fit(const ScanArgs& a) { return a.wkind == 1 || ((long)a.T + 64) * a.C < (1L << 30); }
+
 hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
 {
+    if (!offsets_fit(a_)) return hipErrorInvalidValue;
 #ifdef WKV6_STAMP
     ScanArgs a = a_;
     a.aux = reinterpret_cast<float*>(g_stamp_buffer);
@@ -389,6 +401,7 @@ hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
 // state recurrence only, dumping the group-entry states into a.ckpt (first half of the self-contained backward)
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st)
 {
+    if (!offsets_fit(a)) return hipErrorInvalidValue;
     return a.wkind == 1 ? launch_fwd_variant<true, true, false>(a, st) : launch_fwd_variant<false, true, false>(a, st);
 }
 

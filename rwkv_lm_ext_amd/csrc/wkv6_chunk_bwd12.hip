@@ -68,7 +68,11 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
     lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
 }
 
-template <bool W_RAW>
+// GEN = false: gradients are plain bf16 stores (buffer stores, tokens past the end dropped by the hardware): no store-mode
+// branches at all.  GEN = true: the wkv6_bi halves (fp32 side buffers / accumulation) and tail zeroing.  (With the branches in
+// one kernel hipcc merges the "a load may be pending" state of the accumulate path into the plain path and drains the
+// vector-memory queue -- s_waitcnt vmcnt(0) -- around every plain store: backward 0.48 -> 0.58 ms.)
+template <bool W_RAW, bool GEN>
 __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][BBLK_BYTES] | checkpoint queue
@@ -91,20 +95,28 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const RevMap tokmap = make_revmap(a, b, ntok);
-    // gradient store: plain; or (wkv6_bi) first half into the fp32 side buffer, second half adds it and rounds once
-    auto emit = [&](int which, bf16_t* out, unsigned idx, float (&o)[4]) {
-        float* const side = a.g_f32[which];
+    // buffer resources over this row's first ntok tokens (wkv6_common.h): loads past the end return 0, stores are dropped
+    const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
+    const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);
+    // gradient store of scan position p, channels ch..ch+3: plain; or (wkv6_bi) first half into the fp32 side buffer, second half
+    // adds it and rounds once
+    auto emit = [&](int which, const rsrc_t& rs, bf16_t* out, int p, unsigned bit, int ch, float (&o)[4]) {
+        const unsigned idx = (unsigned)(tokmap(p, bit) * a.C + ch);
+        float* const side = GEN ? a.g_f32[which] : nullptr;
+        if (!GEN || (!side && !a.accumulate)) {
+            buf_store8(rs, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
+            return;
+        }
+        if (p >= ntok) return;
         if (side && !a.accumulate) {
             io4<float>::store(side + base + idx, o);
             return;
         }
-        if (a.accumulate) {
-            float old[4];
-            if (side) io4<float>::load(side + base + idx, old);
-            else io4<bf16_t>::load(out + idx, old);
+        float old[4];
+        if (side) io4<float>::load(side + base + idx, old);
+        else io4<bf16_t>::load(out + idx, old);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] += old[q];
-        }
+        for (int q = 0; q < 4; ++q) o[q] += old[q];
         io4<bf16_t>::store(out + idx, o);
     };
 
@@ -119,23 +131,22 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 
     uint2 pr[2], pk[2], pv[2], pg[2], pw[2];
     float4 pe[2];
-    auto load_group = [&](int grp) {   // grp = stage index here
+    const rsrc_t rs_r = make_rsrc(gr_, nbytes), rs_k = make_rsrc(gk_, nbytes), rs_v = make_rsrc(gv_, nbytes), rs_g = make_rsrc(ggy, nbytes);
+    const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, nbytes)
+                              : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? (unsigned)(ntok - 1) * a.C * 4u + 256u : 0u);
+    auto load_group = [&](int grp) {   // grp = stage index here; tokens past the end load zeros
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int p = grp * STG + pb * BLK + 2 * tq + tt;
-            pr[tt] = pk[tt] = pv[tt] = pg[tt] = pw[tt] = make_uint2(0u, 0u);
-            pe[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < ntok) {
-                const unsigned ir = (unsigned)(tokmap(p, REV_R) * a.C + ch0), ik = (unsigned)(tokmap(p, REV_K) * a.C + ch0);
-                const unsigned iv = (unsigned)(tokmap(p, REV_V) * a.C + ch0), iw = (unsigned)(tokmap(p, REV_W) * a.C + ch0);
-                const unsigned ig = (unsigned)(tokmap(p, REV_Y) * a.C + ch0);
-                pr[tt] = *reinterpret_cast<const uint2*>(gr_ + ir);
-                pk[tt] = *reinterpret_cast<const uint2*>(gk_ + ik);
-                pv[tt] = *reinterpret_cast<const uint2*>(gv_ + iv);
-                pg[tt] = *reinterpret_cast<const uint2*>(ggy + ig);
-                if constexpr (W_RAW) pw[tt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.w) + base + iw);
-                else pe[tt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.w) + base + iw);
-            }
+            const unsigned ir = (unsigned)(tokmap(p, REV_R) * a.C + ch0), ik = (unsigned)(tokmap(p, REV_K) * a.C + ch0);
+            const unsigned iv = (unsigned)(tokmap(p, REV_V) * a.C + ch0), iw = (unsigned)(tokmap(p, REV_W) * a.C + ch0);
+            const unsigned ig = (unsigned)(tokmap(p, REV_Y) * a.C + ch0);
+            pr[tt] = buf_load8(rs_r, ir * 2u);
+            pk[tt] = buf_load8(rs_k, ik * 2u);
+            pv[tt] = buf_load8(rs_v, iv * 2u);
+            pg[tt] = buf_load8(rs_g, ig * 2u);
+            if constexpr (W_RAW) pw[tt] = buf_load8(rs_w, iw * 2u);
+            else pe[tt] = buf_load16f(rs_w, iw * 4u);
         }
     };
 
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         };
         const int qrd = (8 * (4 * (g >> 1)) + 4 * (g & 1) + (x >> 2)) * 16 + (x & 3) * 4;   // read-back: + jt 1024 + q 128
         if (ngrp > 0) request_ckpt(ngrp - 1);
-        const bool plain_stores = !a.accumulate && !a.g_f32[0] && !a.g_f32[1] && !a.g_f32[3];   // emit = one store, no load
+        const bool plain_stores = !GEN || (!a.accumulate && !a.g_f32[0] && !a.g_f32[1] && !a.g_f32[3]);   // emit = one store, no load
         int later = 0;
 
         __syncthreads();                                          // first stage image is ready
@@ -332,8 +343,9 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             // stage-entry forward state: read back what this wave requested a stage ago, then request the next one.
             // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here.  It was issued a whole stage ago,
             // but this wave's gradient stores of that stage were issued after it and vmcnt retires in order: waiting for
-            // vmcnt(0) would also wait for the acknowledgement of stores issued a few hundred cycles ago.  When the previous
-            // stage issued exactly its six plain stores (gr, gk, gw of two blocks), wait until only those are outstanding.
+            // vmcnt(0) would also wait for the acknowledgement of stores issued a few hundred cycles ago.  In plain-store mode a
+            // stage issues exactly six of them (gr, gk, gw of two blocks; on gfx9 vmcnt retires loads and stores in issue order,
+            // which is also what hipcc's own counted waits assume): wait until only those are outstanding.
             if (later == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (grp > 0) request_ckpt(grp - 1);
 #ifndef WKV6_VMCNT0                                                  // (ablation switch: always drain)
-            later = (plain_stores && (grp + 1) * STG <= ntok) ? 6 : 0;   // vector-memory instructions this stage issues after the request
+            later = plain_stores ? 6 : 0;   // vector-memory instructions this stage issues after the request (buffer stores: never skipped)
 #endif
             WKV6_T(ts2);
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                         at[blk][q] = rv[q] * dq;
                     }
                     const int p = grp * STG + blk * BLK + x;
-                    if (p < ntok) emit(0, ogr, (unsigned)(tokmap(p, REV_R) * a.C + ch), o_gr);
+                    emit(0, rs_gr, ogr, p, REV_R, ch, o_gr);
                 }
             }
             WKV6_T(ts3);
@@ -531,10 +543,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                         Rc[q] += total;
                     }
                     const int p = grp * STG + blk * BLK + x;
-                    if (p < ntok) {
-                        emit(1, ogk, (unsigned)(tokmap(p, REV_K) * a.C + ch), o_gk);
-                        emit(3, ogw, (unsigned)(tokmap(p, REV_W) * a.C + ch), o_gw);
-                    }
+                    emit(1, rs_gk, ogk, p, REV_K, ch, o_gk);
+                    emit(3, rs_gw, ogw, p, REV_W, ch, o_gw);
                 }
                 // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
@@ -650,10 +660,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                 acc += accp[blk];
                 {
                     const int p = grp * STG + blk * BLK + x;
-                    if (p < ntok) {
-                        float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-                        emit(2, ogv, (unsigned)(tokmap(p, REV_V) * a.C + 16 * wv + 4 * g), o);
-                    }
+                    float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+                    emit(2, rs_gv, ogv, p, REV_V, 16 * wv + 4 * g, o);
                 }
                 // ---- G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
@@ -686,7 +694,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
     }
 #endif
-    if (a.zero_tail && !a.accumulate) {
+    if (GEN && a.zero_tail && !a.accumulate) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += 48) {
             const unsigned idx = (unsigned)(t * a.C + 4 * (tid & 15));
@@ -698,14 +706,19 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     }
 }
 
-template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStream_t st)
+template <bool W_RAW, bool GEN> hipError_t launch_bwd12_inst(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = BWD12_LDS;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static LdsAttrOnce attr;                   // per instantiation and device
-    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW>), lds)) return e;
-    hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW>), dim3(a.B * a.H), dim3(768), lds, st, a);
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW, GEN>), lds)) return e;
+    hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW, GEN>), dim3(a.B * a.H), dim3(768), lds, st, a);
     return hipGetLastError();
+}
+template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStream_t st)
+{
+    const bool gen = a.accumulate || a.zero_tail || a.g_f32[0] || a.g_f32[1] || a.g_f32[2] || a.g_f32[3];
+    return gen ? launch_bwd12_inst<W_RAW, true>(a, st) : launch_bwd12_inst<W_RAW, false>(a, st);
 }
 
 }  // namespace
@@ -715,6 +728,7 @@ hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // wkv6
 hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
 {
     if (a.ckpt_tok != STG) return hipErrorInvalidValue;
+    if (a.wkind != 1 && ((long)a.T + 64) * a.C >= (1L << 30)) return hipErrorInvalidValue;   // 32-bit byte offsets of the fp32 decay input
     if (!a.ckpt_valid) {                   // self-contained backward: state pass first (same inputs, no outputs)
         ScanArgs sp = a;
         sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;

@@ -20,6 +20,32 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi)
     return __builtin_bit_cast(uint32_t, h);
 }
 
+// ---- buffer-resource access: a 128-bit descriptor (base, byte count) in SGPRs + a 32-bit byte offset per lane.  Against
+// flat global_load/store this saves the 64-bit address arithmetic per access, and the hardware drops accesses at or past the
+// byte count (loads return 0), which replaces the per-lane "token < length" predicates with their exec-mask branches.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, gfx9 flags
+}
+__device__ __forceinline__ uint2 buf_load8(rsrc_t r, unsigned off)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ float4 buf_load16f(rsrc_t r, unsigned off)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void buf_store8(rsrc_t r, unsigned off, uint2 v)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(v2u{v.x, v.y}, r, (int)off, 0, 0);
+}
+
 // ---- 4-wide channel I/O in the operator's I/O type (bf16 or float) ------------------------------
 template <typename T> struct io4;
 template <> struct io4<bf16_t> {
