@@ -102,22 +102,24 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     // adds it and rounds once
     auto emit = [&](int which, const rsrc_t& rs, bf16_t* out, int p, unsigned bit, int ch, float (&o)[4]) {
         const unsigned idx = (unsigned)(tokmap(p, bit) * a.C + ch);
-        float* const side = GEN ? a.g_f32[which] : nullptr;
-        if (!GEN || (!side && !a.accumulate)) {
+        if constexpr (!GEN) {
             buf_store8(rs, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
-            return;
-        }
-        if (p >= ntok) return;
-        if (side && !a.accumulate) {
-            io4<float>::store(side + base + idx, o);
-            return;
-        }
-        float old[4];
-        if (side) io4<float>::load(side + base + idx, old);
-        else io4<bf16_t>::load(out + idx, old);
+        } else {
+            if (p >= ntok) return;
+            float* const side = a.g_f32[which];
+            if (side && !a.accumulate) {
+                io4<float>::store(side + base + idx, o);
+                return;
+            }
+            if (a.accumulate) {
+                float old[4];
+                if (side) io4<float>::load(side + base + idx, old);
+                else io4<bf16_t>::load(out + idx, old);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] += old[q];
-        io4<bf16_t>::store(out + idx, o);
+                for (int q = 0; q < 4; ++q) o[q] += old[q];
+            }
+            io4<bf16_t>::store(out + idx, o);
+        }
     };
 
 #ifdef WKV6_STAMP
