@@ -7,9 +7,10 @@ from . import _build
 
 _SHIM_SRC = os.path.join(_build.CSRC, "torch_shim", "wkv6_torch_shim.cpp")
 _INCLUDE = os.path.join(os.path.dirname(_build.PKG_DIR), "include")
+BUILD_DIR = os.path.join(_build.PKG_DIR, "torch_shim_build")      # in-tree, so that the built module travels with the repo
 
 
-def load(prefix="shim", verbose=False, build_directory=None):
+def load(prefix="shim", verbose=False, build_directory=BUILD_DIR):
     """Returns the extension module: `.wkv6.forward(B,T,C,H,r,k,v,ew,u,y)`, `.wkv6.backward(...)`, `.wkv6_bi`, `.wkv6state`,
     `.wkv6infctx`, `.rwkv6`; also registers torch.ops.<prefix>_wkv6 etc. (prefix=None: the reference's bare names, only in
     a process that has not imported rwkv_lm_ext_amd.wkv6_op, which defines torch.ops.wkv6* itself)."""

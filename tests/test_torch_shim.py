@@ -3,7 +3,6 @@ torch + ROCm, links librwkv6_amd.so, exposes the reference's pybind functions an
 (cuda/wkv6_op.cpp:8-22, wkv6_bi_op.cpp, wkv6state_op.cpp, wkv6infctx_op.cpp, rwkv6_op.cpp).  The CPU test builds and
 inspects it; the GPU test calls through it and compares with the oracle."""
 import os
-import tempfile
 
 import numpy as np
 import pytest
@@ -11,13 +10,12 @@ import torch
 
 from conftest import max_norm_err
 
-_BUILD_DIR = os.path.join(tempfile.gettempdir(), "rwkv6_torch_shim_build")
 
 
 @pytest.fixture(scope="module")
 def shim():
     from rwkv_lm_ext_amd import torch_shim
-    return torch_shim.load(prefix="shim", build_directory=_BUILD_DIR)
+    return torch_shim.load(prefix="shim")
 
 
 def test_shim_builds_and_registers_every_operator(shim):
