@@ -89,8 +89,11 @@ enum {
     WKV6_CKPT_VALID = 32,   /* backward: `workspace` already holds the checkpoints written by wkv6_forward_ckpt_ex
                                (wkv6_bi: by wkv6bi_forward_ex with WKV6_BI_KEEP_CKPT) for the same inputs, so the backward
                                skips its own state pass(es) */
-    WKV6_BI_KEEP_CKPT = 64  /* wkv6bi_forward_ex: also store the state checkpoints of both scans in `workspace` (which the
+    WKV6_BI_KEEP_CKPT = 64, /* wkv6bi_forward_ex: also store the state checkpoints of both scans in `workspace` (which the
                                caller then hands to wkv6bi_backward_ex with WKV6_CKPT_VALID) */
+    WKV6_PARTIALS_F32 = 128 /* backward: gu [B,C] and gs [B,H,N,N] are fp32 buffers -- they are per-batch partial sums that the
+                               caller reduces over the batch, so keeping them unrounded lets the parameter gradient be rounded
+                               once (the reference ABI, bf16 partials, rounds twice: src/model.py:181, 232) */
 };
 /* Bytes of scratch the backward needs (the forward needs none). */
 size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H);

@@ -48,7 +48,7 @@ SIGNATURES = {
 }
 
 # flags of include/wkv6_amd.h
-W_EW_F32, W_RAW, IO_F32, S0_PER_BATCH, ALGO_SCAN, CKPT_VALID, BI_KEEP_CKPT = 0, 1, 2, 4, 16, 32, 64
+W_EW_F32, W_RAW, IO_F32, S0_PER_BATCH, ALGO_SCAN, CKPT_VALID, BI_KEEP_CKPT, PARTIALS_F32 = 0, 1, 2, 4, 16, 32, 64, 128
 REV_R, REV_K, REV_V, REV_W, REV_Y, REV_ALL = 1, 2, 4, 8, 16, 31      # wkv6_*_rev_ex: tensors held in reversed order
 
 ERRORS = {-1: "WKV6_EINVAL (shape: need C == H*64 and B,T,C,H >= 1)", -2: "WKV6_ENULL (null pointer)",

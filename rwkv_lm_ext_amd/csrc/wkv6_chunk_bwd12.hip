@@ -563,7 +563,11 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             float s4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) s4[q] = row_sum16(gu_acc[q]);
-            if (x == 0) io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.gu) + (long)b * a.C + h * HEAD + 16 * wv + 4 * g, s4);
+            const long o = (long)b * a.C + h * HEAD + 16 * wv + 4 * g;
+            if (x == 0) {
+                if (a.part_f32) io4<float>::store(reinterpret_cast<float*>(a.gu) + o, s4);
+                else io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.gu) + o, s4);
+            }
         }
     } else {
         // =============== value columns [16wv, 16wv+16): scores, gv, gs ======================================
@@ -682,11 +686,12 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2);
         }
         if (a.gs) {   // dL/dS0, layout [j][i]
-            bf16_t* const og = reinterpret_cast<bf16_t*>(a.gs) + ((long)b * a.H + h) * HEAD * HEAD;
+            const long so_ = ((long)b * a.H + h) * HEAD * HEAD + (long)(16 * wv + x) * HEAD + 8 * g;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const float t4[4] = {GJ[it][0], GJ[it][1], GJ[it][2], GJ[it][3]};
-                io4<bf16_t>::store(og + (long)(16 * wv + x) * HEAD + tile_ch(it) + 8 * g, t4);
+                if (a.part_f32) io4<float>::store(reinterpret_cast<float*>(a.gs) + so_ + tile_ch(it), t4);
+                else io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.gs) + so_ + tile_ch(it), t4);
             }
         }
     }

@@ -404,9 +404,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_s_kernel(const ScanArgs a)
             float s = 0.f;
 #pragma unroll
             for (int pp = 0; pp < TB; ++pp) s += dqs[pp * ROW + tid];
-            T* const og = reinterpret_cast<T*>(a.gu) + (long)b * a.C + h * HEAD + tid;
-            if constexpr (sizeof(T) == 2) *og = (T)(pack_bf2(s, 0.f) & 0xffffu);
-            else *og = s;
+            const long o = (long)b * a.C + h * HEAD + tid;
+            if (sizeof(T) == 4 || a.part_f32) reinterpret_cast<float*>(a.gu)[o] = s;
+            else reinterpret_cast<bf16_t*>(a.gu)[o] = (bf16_t)(pack_bf2(s, 0.f) & 0xffffu);
         }
     }
 }
@@ -637,13 +637,14 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_g_kernel(const ScanArgs a)
     finish_gw();                                       // batch 0
 
     if (a.gs) {
-        T* const og = reinterpret_cast<T*>(a.gs) + ((long)b * a.H + h) * HEAD * HEAD;
+        const long so_ = ((long)b * a.H + h) * HEAD * HEAD;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             float t2[IR];
 #pragma unroll
             for (int ii = 0; ii < IR; ++ii) t2[ii] = Gs[ii][jj];
-            ion<T, IR>::store(og + (long)(j0 + jj) * HEAD + i0, t2);
+            if (sizeof(T) == 4 || a.part_f32) ion<float, IR>::store(reinterpret_cast<float*>(a.gs) + so_ + (long)(j0 + jj) * HEAD + i0, t2);
+            else ion<T, IR>::store(reinterpret_cast<T*>(a.gs) + so_ + (long)(j0 + jj) * HEAD + i0, t2);
         }
     }
     if (a.zero_tail && !a.accumulate) {

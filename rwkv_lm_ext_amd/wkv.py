@@ -149,7 +149,7 @@ class WKV_6STATE_INFCTX(torch.autograd.Function):
             ctx.ckpt = None
             # the reference sums gs over the batch to [H,N,N] although s is per sample (src/model.py:126);
             # the per-sample gradient is the mathematically correct one for a per-sample state
-            return (None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (H, N)), gs)
+            return (None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (H, N)), gs.to(torch.bfloat16))
 
 
 def RUN_CUDA_RWKV6_STATE(B, T, C, H, r, k, v, w, u, s):

@@ -243,7 +243,8 @@ def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None, alg
 
 
 def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False, algo=None, ckpt=None):
-    """Returns (gr, gk, gv, gw, gu[B,C], gs[B,H,N,N] or None) in the I/O type of `r`."""
+    """Returns (gr, gk, gv, gw, gu[B,C], gs[B,H,N,N] or None): gradients in the I/O type of `r`, the per-batch partials gu / gs
+    in fp32 (WKV6_PARTIALS_F32)."""
     B, T, C = r.shape
     io = r.dtype
     btc = (B, T, C)
@@ -258,8 +259,10 @@ def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False, alg
         flags |= _lib.S0_PER_BATCH if per_batch else 0
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
-    gu = torch.empty((B, C), device=dev, dtype=io)
-    gs = torch.empty((B, H, HEAD_SIZE, HEAD_SIZE), device=dev, dtype=io) if want_gs else None
+    # gu / gs are per-batch partial sums the caller reduces: always fp32, so that the parameter gradient is rounded once
+    flags |= _lib.PARTIALS_F32
+    gu = torch.empty((B, C), device=dev, dtype=torch.float32)
+    gs = torch.empty((B, H, HEAD_SIZE, HEAD_SIZE), device=dev, dtype=torch.float32) if want_gs else None
     if ckpt is not None:           # checkpoints written by forward_ex(..., ckpt=ckpt) on the same inputs
         ws = ckpt
         flags |= _lib.CKPT_VALID
@@ -311,8 +314,8 @@ def backward_rev_ex(r, k, v, w, u, gy, H, rev_n, rev_mask, ckpt=None):
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     _check_rev(B, rev_n, rev_mask, dev)
     gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
-    gu = torch.empty((B, C), device=dev, dtype=io)
-    flags = _lib.W_RAW
+    gu = torch.empty((B, C), device=dev, dtype=torch.float32)
+    flags = _lib.W_RAW | _lib.PARTIALS_F32
     if ckpt is not None:
         ws = ckpt
         flags |= _lib.CKPT_VALID
@@ -368,7 +371,8 @@ def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False, algo=None, ws=None
     flags |= _lib.ALGO_SCAN if algo == "scan" else 0
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
-    gu = torch.empty((B, C), device=dev, dtype=io)
+    gu = torch.empty((B, C), device=dev, dtype=torch.float32)      # per-batch partials: fp32 (WKV6_PARTIALS_F32)
+    flags |= _lib.PARTIALS_F32
     if ws is not None and io == torch.bfloat16 and algo != "scan":
         flags |= _lib.CKPT_VALID
     elif ws is None:

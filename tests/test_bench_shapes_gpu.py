@@ -89,7 +89,7 @@ def test_config2_chunked_fwd_bwd_vs_oracle_slices(ops, oracle):
         og = oracle.backward(rs, ks, vs, ws, us, gys)
         for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
             check_bf16(t[sl], og[n], f"config2 ({b},{h}) {n}")
-        assert max_norm_err(host(gu[b, 64 * h:64 * h + 64]), og["gu_b"][0]) <= 8e-3
+        assert max_norm_err(host(gu[b, 64 * h:64 * h + 64]), og["gu_b"][0]) <= 1e-3      # fp32 partials (WKV6_PARTIALS_F32)
     # whole tensor: chunked (default) vs exact scan kernels in bf16
     ys = ops.forward_ex(r, k, v, w, u, H, algo="scan")
     agree_with_scan(y, ys, "y")
@@ -119,7 +119,7 @@ def test_config3_wkv6_bi_ragged_vs_oracle_slices(ops, oracle):
         og = oracle.bi_backward(mh[b:b + 1], rs, ks, vs, ws, us, gys)
         for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
             check_bf16(t[sl], og[n], f"bi ({b},{h}) {n}")
-        assert max_norm_err(host(gu[b, 64 * h:64 * h + 64]), og["gu_b"][0]) <= 8e-3
+        assert max_norm_err(host(gu[b, 64 * h:64 * h + 64]), og["gu_b"][0]) <= 1e-3      # fp32 partials (WKV6_PARTIALS_F32)
         L = int(lens[b])
         if L < T:                                                   # Q2: zero beyond the first masked token
             assert float(y[b, L:].abs().max()) == 0.0 and float(gk[b, L:].abs().max()) == 0.0
@@ -149,7 +149,7 @@ def test_config5_infctx_carry_vs_oracle_slice(ops, oracle):
         og = oracle.backward(rs, ks, vs, ws, us, gys, s_or)
         for n, t in zip(("gr", "gk", "gv", "gw"), grads[c][:4]):
             check_bf16(t[hs], og[n], f"infctx chunk {c} {n}")
-        check_bf16(grads[c][5][b:b + 1, h:h + 1], og["gs_b"], f"infctx chunk {c} gs")
+        check_bf16(grads[c][5][b:b + 1, h:h + 1].to(torch.bfloat16), og["gs_b"], f"infctx chunk {c} gs")   # fp32 partial, rounded once
         # the carry the kernel wrote (bf16) is the next chunk's entry state, for the oracle too
         check_bf16(states[c + 1][b:b + 1, h:h + 1], so, f"infctx chunk {c} state")
         s_or = host(states[c + 1][b:b + 1, h:h + 1])
