@@ -49,10 +49,15 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform, provably so
+    // a.split (B*H <= half the CUs): two 6-wave workgroups per (batch, head) on two CUs, each with all four producers and two
+    // of the four consumers (value columns [32 part, 32 part + 32)): hardware wave w plays consumer 2 part + w for w < 2 and
+    // producer w - 2 (wave id 4 + w - 2) otherwise.  The preparation is duplicated, on CUs that would otherwise idle.
+    const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform, provably so
+    const int part = a.split ? (int)(blockIdx.x & 1) : 0, bh = a.split ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int wid = a.split ? (hwid < 2 ? 2 * part + hwid : hwid + 2) : hwid;
     const bool producer = wid >= 4;
     const int wv = wid & 3;                                          // block (producer) / column tile (consumer)
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int b = bh / a.H, h = bh % a.H;
     const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
                                                               // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
     const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
                 if (a.ckpt && (blk * BLK) % a.ckpt_tok == 0 && grp * GRP + blk * BLK < a.T) {   // state every ckpt_tok tokens, for the backward kernel
-                    float* const ck = a.ckpt + ((long)blockIdx.x * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) +
+                    float* const ck = a.ckpt + ((long)bh * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) +
                                                 (grp * GRP + blk * BLK) / a.ckpt_tok) * (HEAD * HEAD);
 #pragma unroll
                     for (int it = 0; it < 4; ++it)   // streamed: written once, read once by the backward
@@ -359,13 +364,13 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
     }
 #ifdef WKV6_STAMP
     if (a.aux && lane == 0) {
-        unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)blockIdx.x * 16 + wid) * 8;
+        unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)bh * 16 + wid) * 8;
         for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
     }
 #endif
     if (!STATE_ONLY && !ACC && a.zero_tail) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = ntok + (tid >> 4); t < a.T; t += 32)
+        for (int t = ntok + (tid >> 4); part == 0 && t < a.T; t += (int)(blockDim.x >> 4))
             io4<bf16_t>::store(gy_ + (unsigned)(t * a.C + 4 * (tid & 15)), z);
     }
 }
@@ -375,7 +380,8 @@ template <bool W_RAW, bool STATE_ONLY, bool ACC> hipError_t launch_fwd_variant(c
     constexpr size_t lds = 2 * (size_t)GRP_BYTES;
     static LdsAttrOnce attr;                   // per instantiation and device
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), lds)) return e;
-    hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), dim3(a.B * a.H), dim3(512), lds, st, a);
+    if (a.split) hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), dim3(2 * a.B * a.H), dim3(384), lds, st, a);
+    else hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), dim3(a.B * a.H), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -384,14 +390,15 @@ template <bool W_RAW, bool STATE_ONLY, bool ACC> hipError_t launch_fwd_variant(c
 // per-lane byte offsets are 32-bit: bf16 tensors need (T + 64) C < 2^31 (checked by the API), the fp32 decay input half of that
 static bool offsets_fit(const ScanArgs& a) { return a.wkind == 1 || ((long)a.T + 64) * a.C < (1L << 30); }
 
+int want_split(int BH);     // wkv6_chunk_bwd12.hip
+
 hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
 {
     if (!offsets_fit(a_)) return hipErrorInvalidValue;
-#ifdef WKV6_STAMP
     ScanArgs a = a_;
+    a.split = want_split(a.B * a.H);
+#ifdef WKV6_STAMP
     a.aux = reinterpret_cast<float*>(g_stamp_buffer);
-#else
-    const ScanArgs& a = a_;
 #endif
     const bool raw = a.wkind == 1;          // 0: fp32 ew = -exp(w), 1: raw w in bf16, 2: fp32 decay exp(-exp(w))
     if (a.accumulate) return raw ? launch_fwd_variant<true, false, true>(a, st) : launch_fwd_variant<false, false, true>(a, st);
@@ -399,9 +406,11 @@ hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
 }
 
 // state recurrence only, dumping the group-entry states into a.ckpt (first half of the self-contained backward)
-hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st)
+hipError_t launch_chunk_state_pass(const ScanArgs& a_, hipStream_t st)
 {
-    if (!offsets_fit(a)) return hipErrorInvalidValue;
+    if (!offsets_fit(a_)) return hipErrorInvalidValue;
+    ScanArgs a = a_;
+    a.split = want_split(a.B * a.H);
     return a.wkind == 1 ? launch_fwd_variant<true, true, false>(a, st) : launch_fwd_variant<false, true, false>(a, st);
 }
 

@@ -77,11 +77,17 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][BBLK_BYTES] | checkpoint queue
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // a.split (few (batch, head) pairs, B*H <= half the CUs): the row role and the column role -- which share nothing but the
+    // stage images -- run as two 8-wave workgroups on two CUs, each with its own four producers (duplicated preparation on
+    // otherwise idle CUs); hardware wave w of workgroup part p plays wave w (p = 0) / 4 + w (p = 1) for w < 4 and producer
+    // 8 + (w - 4) for w >= 4.
+    const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = a.split ? (int)(blockIdx.x & 1) : 0, bh = a.split ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int wid = a.split ? (hwid < 4 ? hwid + 4 * part : hwid + 4) : hwid;
     const bool rowrole = wid < 4, producer = wid >= 8;
     const int wv = wid & 3;                                              // tile owned by a row / column wave
     const int pb = wid & 1, half = (wid >> 1) & 1;                       // producer: block of the stage, channel half
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int b = bh / a.H, h = bh % a.H;
     const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
                                                               // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
     const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         const unsigned qbase = __builtin_amdgcn_readfirstlane(
             (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)qreg));   // LDS byte address, wave-uniform
         auto request_ckpt = [&](int stg) {
-            const float* const ck = a.ckpt + ((long)blockIdx.x * nstmax + stg) * (HEAD * HEAD);
+            const float* const ck = a.ckpt + ((long)bh * nstmax + stg) * (HEAD * HEAD);
             const int fm = lane & 3, fgl = (lane >> 2) & 1, fp = (lane >> 3) & 3, fgh = lane >> 5;   // this lane as a fetch lane
             const int i0 = 16 * wv + 4 * fm, gq = 2 * fgh + fgl;
             const int fit = 2 * (i0 >> 5) + ((i0 >> 2) & 1), fg = (i0 >> 3) & 3;
@@ -697,13 +703,13 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     }
 #ifdef WKV6_STAMP
     if (a.aux && lane == 0) {
-        unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)blockIdx.x * 16 + wid) * 8;
+        unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)bh * 16 + wid) * 8;
         for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
     }
 #endif
-    if (GEN && a.zero_tail && !a.accumulate) {
+    if (GEN && a.zero_tail && !a.accumulate && part == 0) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = ntok + (tid >> 4); t < a.T; t += 48) {
+        for (int t = ntok + (tid >> 4); t < a.T; t += (int)(blockDim.x >> 4)) {
             const unsigned idx = (unsigned)(t * a.C + 4 * (tid & 15));
             io4<bf16_t>::store(ogr + idx, z);
             io4<bf16_t>::store(ogk + idx, z);
@@ -719,7 +725,8 @@ template <bool W_RAW, bool GEN> hipError_t launch_bwd12_inst(const ScanArgs& a, 
     static_assert(lds <= 160 * 1024, "LDS budget");
     static LdsAttrOnce attr;                   // per instantiation and device
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW, GEN>), lds)) return e;
-    hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW, GEN>), dim3(a.B * a.H), dim3(768), lds, st, a);
+    if (a.split) hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW, GEN>), dim3(2 * a.B * a.H), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW, GEN>), dim3(a.B * a.H), dim3(768), lds, st, a);
     return hipGetLastError();
 }
 template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStream_t st)
@@ -732,8 +739,25 @@ template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStre
 
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // wkv6_chunk.hip
 
-hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st)
+// two workgroups per (batch, head) when one each would leave at least half of the CUs without work
+int want_split(int BH)
 {
+    static int cus[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus[dev] = prop.multiProcessorCount;
+    }
+    if (const char* e = getenv("WKV6_SPLIT")) return atoi(e) != 0;     // A/B switch
+    return 2 * BH <= cus[dev];
+}
+
+hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)
+{
+    ScanArgs a = a_;
+    a.split = want_split(a.B * a.H);
     if (a.ckpt_tok != STG) return hipErrorInvalidValue;
     if (a.wkind != 1 && ((long)a.T + 64) * a.C >= (1L << 30)) return hipErrorInvalidValue;   // 32-bit byte offsets of the fp32 decay input
     if (!a.ckpt_valid) {                   // self-contained backward: state pass first (same inputs, no outputs)

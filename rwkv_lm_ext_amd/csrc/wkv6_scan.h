@@ -73,6 +73,8 @@ struct ScanArgs {
     int use_u;                        // 0: bonus u treated as 0 (reverse half of wkv6_bi)
     int accumulate;                   // 1: add into y / gr,gk,gv,gw instead of overwriting
     int zero_tail;                    // 1: write zeros for tokens >= lens[b]
+    int split;                        // chunked kernels, set by the launcher when B*H leaves half the chip idle: two workgroups per
+                                      // (batch, head), each with its own producers and half of the consuming waves
 };
 
 enum { REV_R = 1, REV_K = 2, REV_V = 4, REV_W = 8, REV_Y = 16, REV_ALL = 31 };   // REV_Y: y in the forward, gy in the backward;

@@ -241,6 +241,29 @@ def test_autograd_surface(ops, oracle):
     check(leaves[1].grad, ob["gk"], bf, "WKV_6_BI gk")
 
 
+def test_two_workgroups_per_head_is_the_same_arithmetic(ops, monkeypatch):
+    """Few (batch, head) pairs (B*H <= half the CUs) run as two workgroups per pair -- forward: two consumer waves each, backward:
+    row role / column role -- with the same per-wave arithmetic: every output is bit-identical to the one-workgroup launch
+    (WKV6_SPLIT forces either; the default picks by grid size, so the suite's small cases run split and the full-size ones not)."""
+    bf = torch.bfloat16
+    B, T, H = 3, 200, 2
+    r, k, v, w, u, gy = rand_inputs(11, B, T, H)
+    g = torch.Generator().manual_seed(3)
+    s0 = dev((torch.randn(B, H, 64, 64, generator=g) * 0.5).numpy(), bf)
+    d = [dev(x, bf) for x in (r, k, v, w, u)]
+    res = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("WKV6_SPLIT", split)
+        s_out = torch.empty_like(s0)
+        ck = ops.new_checkpoint(B, T, 64 * H, H, s0.device)
+        y = ops.forward_ex(*d, H, s0=s0, s_out=s_out, ckpt=ck)
+        grads = ops.backward_ex(*d, dev(gy, bf), H, s0=s0, want_gs=True, ckpt=ck)
+        grads2 = ops.backward_ex(*d, dev(gy, bf), H, s0=s0, want_gs=True)          # own state pass
+        res.append([y, s_out] + list(grads) + list(grads2))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_checkpoint_opt_out_gives_identical_gradients(ops, monkeypatch):
     """RWKV_AMD_NO_CKPT=1: nothing is kept from forward to backward, the backward rebuilds the state checkpoints itself --
     same kernels on the same numbers, so every gradient is bit-identical (WKV_6 and WKV_6_BI)."""
