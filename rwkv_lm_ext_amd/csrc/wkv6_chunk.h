@@ -35,6 +35,11 @@ constexpr int OFF_COEF = OFF_E16M8 + 256;              // float[16]  sum_i r u k
 constexpr int OFF_SC = OFF_COEF + 16 * 4;              // uint4 [64]  masked scores^T, bf16x4 hi | bf16x4 lo: the B fragment of each lane
 constexpr int BLK_BYTES = OFF_SC + 2 * 64 * 8;
 constexpr float LW_MIN = -9.0f;
+// The producers keep the log-decays in log2 units (lw * log2 e): every later exponential is then a bare v_exp_f32 (= 2^x)
+// instead of v_mul + v_exp, at one extra multiply per token-channel where lw is formed.
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr float LW_MIN2 = LW_MIN * LOG2E;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // State tiles are 16x16 C-layout MFMA tiles; tile t = 2s + hb, row rho = 4g + q of a tile stands for channel
 //     tile_ch(t) + 8g + q        with   tile_ch(t) = 32 (t >> 1) + 4 (t & 1)

@@ -110,18 +110,22 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
                 float lw[4];
                 if constexpr (W_RAW) {
-                    lw[0] = -__expf(bf_lo(pw[tt].x)); lw[1] = -__expf(bf_hi(pw[tt].x));
-                    lw[2] = -__expf(bf_lo(pw[tt].y)); lw[3] = -__expf(bf_hi(pw[tt].y));
+                    // lw = -exp(w), in log2 units: -(log2 e) 2^{w log2 e}
+                    lw[0] = -LOG2E * exp2_fast(LOG2E * bf_lo(pw[tt].x)); lw[1] = -LOG2E * exp2_fast(LOG2E * bf_hi(pw[tt].x));
+                    lw[2] = -LOG2E * exp2_fast(LOG2E * bf_lo(pw[tt].y)); lw[3] = -LOG2E * exp2_fast(LOG2E * bf_hi(pw[tt].y));
                 } else {
                     lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
                     if (a.wkind == 2) {   // the inference entry points pass the decay d = exp(-exp(w)) itself (cuda/rwkv6.cu:38)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) lw[c] = __logf(lw[c]);   // d = 0 -> -inf -> clamped below
+                        for (int c = 0; c < 4; ++c) lw[c] = __builtin_amdgcn_logf(lw[c]);   // log2 d; d = 0 -> -inf -> clamped below
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) lw[c] *= LOG2E;
                     }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float l = valid ? fmaxf(lw[c], LW_MIN) : 0.f;
+                    const float l = valid ? fmaxf(lw[c], LW_MIN2) : 0.f;      // log2 units from here on
                     cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + l;          // inclusive, within this lane's 4 tokens
                 }
                 if constexpr (!STATE_ONLY) {
@@ -151,11 +155,11 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             }
             if (tq == 0) {
                 *reinterpret_cast<float4*>(bb + OFF_E8 + 16 * c4) =
-                    make_float4(__expf(c8[0]), __expf(c8[1]), __expf(c8[2]), __expf(c8[3]));
+                    make_float4(exp2_fast(c8[0]), exp2_fast(c8[1]), exp2_fast(c8[2]), exp2_fast(c8[3]));
                 *reinterpret_cast<float4*>(bb + OFF_E16 + 16 * c4) =
-                    make_float4(__expf(c16[0]), __expf(c16[1]), __expf(c16[2]), __expf(c16[3]));
+                    make_float4(exp2_fast(c16[0]), exp2_fast(c16[1]), exp2_fast(c16[2]), exp2_fast(c16[3]));
                 *reinterpret_cast<float4*>(bb + OFF_E16M8 + 16 * c4) =
-                    make_float4(__expf(c16[0] - c8[0]), __expf(c16[1] - c8[1]), __expf(c16[2] - c8[2]), __expf(c16[3] - c8[3]));
+                    make_float4(exp2_fast(c16[0] - c8[0]), exp2_fast(c16[1] - c8[1]), exp2_fast(c16[2] - c8[2]), exp2_fast(c16[3] - c8[3]));
             }
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 for (int c = 0; c < 4; ++c) {
                     const float cex = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
                     const float cin = pre[c] + cs[tt][c];
-                    rh[c] = r[tt][c] * __expf(cex - c8[c]);
-                    kh[c] = k[tt][c] * __expf(c8[c] - cin);
+                    rh[c] = r[tt][c] * exp2_fast(cex - c8[c]);
+                    kh[c] = k[tt][c] * exp2_fast(c8[c] - cin);
                 }
                 char* const row = bb + (4 * tq + tt) * RSB + 8 * c4;
                 uint2 hi, lo;

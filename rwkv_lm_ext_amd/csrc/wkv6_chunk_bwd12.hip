@@ -168,15 +168,15 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
             float lw[4];
             if constexpr (W_RAW) {
-                lw[0] = -__expf(bf_lo(pw[tt].x)); lw[1] = -__expf(bf_hi(pw[tt].x));
-                lw[2] = -__expf(bf_lo(pw[tt].y)); lw[3] = -__expf(bf_hi(pw[tt].y));
+                lw[0] = -exp2_fast(LOG2E * bf_lo(pw[tt].x)); lw[1] = -exp2_fast(LOG2E * bf_hi(pw[tt].x));
+                lw[2] = -exp2_fast(LOG2E * bf_lo(pw[tt].y)); lw[3] = -exp2_fast(LOG2E * bf_hi(pw[tt].y));
             } else {
                 lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
             }
             float lwe[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                lws[tt][c] = valid ? fmaxf(lw[c], LW_MIN) : 0.f;          // the decay the block algebra uses
+                lws[tt][c] = valid ? fmaxf(lw[c] * LOG2E, LW_MIN2) : 0.f;  // the decay the block algebra uses, in log2 units
                 cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + lws[tt][c];
                 // gw multiplier: the true lw, times d_true / d_clamped where the clamp is active (the algebra yields the
                 // exact gradient of the clamped model, d_clamped * X; the true one is d_true * X)
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             }
             if (__builtin_amdgcn_ballot_w64(lwe[0] < LW_MIN || lwe[1] < LW_MIN || lwe[2] < LW_MIN || lwe[3] < LW_MIN)) {   // rare
 #pragma unroll
-                for (int c = 0; c < 4; ++c) lwe[c] *= __expf(fminf(lwe[c] - LW_MIN, 0.f));
+                for (int c = 0; c < 4; ++c) lwe[c] *= exp2_fast(LOG2E * fminf(lwe[c] - LW_MIN, 0.f));
             }
             float part = 0.f;
 #pragma unroll
@@ -230,11 +230,11 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         }
         if (tq == 0) {
             *reinterpret_cast<float4*>(bb + BOFF_E8 + ch0 * 4) =
-                make_float4(__expf(c8[0]), __expf(c8[1]), __expf(c8[2]), __expf(c8[3]));
+                make_float4(exp2_fast(c8[0]), exp2_fast(c8[1]), exp2_fast(c8[2]), exp2_fast(c8[3]));
             *reinterpret_cast<float4*>(bb + BOFF_E16 + ch0 * 4) =
-                make_float4(__expf(c16[0]), __expf(c16[1]), __expf(c16[2]), __expf(c16[3]));
+                make_float4(exp2_fast(c16[0]), exp2_fast(c16[1]), exp2_fast(c16[2]), exp2_fast(c16[3]));
             *reinterpret_cast<float4*>(bb + BOFF_E16M8 + ch0 * 4) =
-                make_float4(__expf(c16[0] - c8[0]), __expf(c16[1] - c8[1]), __expf(c16[2] - c8[2]), __expf(c16[3] - c8[3]));
+                make_float4(exp2_fast(c16[0] - c8[0]), exp2_fast(c16[1] - c8[1]), exp2_fast(c16[2] - c8[2]), exp2_fast(c16[3] - c8[3]));
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             for (int c = 0; c < 4; ++c) {
                 const float cex = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
                 const float cin = pre[c] + cs[tt][c];
-                fr[c] = __expf(cex - c8[c]);
-                fk[c] = __expf(c8[c] - cin);
+                fr[c] = exp2_fast(cex - c8[c]);
+                fk[c] = exp2_fast(c8[c] - cin);
                 rh[c] = r[tt][c] * fr[c];
                 kh[c] = k[tt][c] * fk[c];
             }
