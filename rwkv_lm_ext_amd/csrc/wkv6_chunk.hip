@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
     const int wid = a.split ? (hwid < 2 ? 2 * part + hwid : hwid + 2) : hwid;
     const bool producer = wid >= 4;
     const int wv = wid & 3;                                          // block (producer) / column tile (consumer)
-    const int b = bh / a.H, h = bh % a.H;
+    const int b = a.order ? a.order[bh / a.H] : bh / a.H, h = bh % a.H;
     const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
                                                               // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
     const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
                 if (a.ckpt && (blk * BLK) % a.ckpt_tok == 0 && grp * GRP + blk * BLK < a.T) {   // state every ckpt_tok tokens, for the backward kernel
-                    float* const ck = a.ckpt + ((long)bh * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) +
+                    float* const ck = a.ckpt + ((long)(b * a.H + h) * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) +
                                                 (grp * GRP + blk * BLK) / a.ckpt_tok) * (HEAD * HEAD);
 #pragma unroll
                     for (int it = 0; it < 4; ++it)   // streamed: written once, read once by the backward

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     const bool rowrole = wid < 4, producer = wid >= 8;
     const int wv = wid & 3;                                              // tile owned by a row / column wave
     const int pb = wid & 1, half = (wid >> 1) & 1;                       // producer: block of the stage, channel half
-    const int b = bh / a.H, h = bh % a.H;
+    const int b = a.order ? a.order[bh / a.H] : bh / a.H, h = bh % a.H;
     const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
                                                               // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
     const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         const unsigned qbase = __builtin_amdgcn_readfirstlane(
             (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)qreg));   // LDS byte address, wave-uniform
         auto request_ckpt = [&](int stg) {
-            const float* const ck = a.ckpt + ((long)bh * nstmax + stg) * (HEAD * HEAD);
+            const float* const ck = a.ckpt + ((long)(b * a.H + h) * nstmax + stg) * (HEAD * HEAD);
             const int fm = lane & 3, fgl = (lane >> 2) & 1, fp = (lane >> 3) & 3, fgh = lane >> 5;   // this lane as a fetch lane
             const int i0 = 16 * wv + 4 * fm, gq = 2 * fgh + fgl;
             const int fit = 2 * (i0 >> 5) + ((i0 >> 2) & 1), fg = (i0 >> 3) & 3;

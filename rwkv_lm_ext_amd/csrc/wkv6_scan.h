@@ -66,6 +66,8 @@ struct ScanArgs {
     int ckpt_tok;                     // tokens between checkpoints (CKPT_TOK)
     int ckpt_valid;                   // backward: ckpt was filled by the forward, skip the state pass
     const int* lens;                  // per-batch number of tokens to scan (null: T)
+    const int* order;                 // chunked kernels: batch row served by workgroup slot blockIdx / H (null: identity) -- rows
+                                      // sorted by decreasing length, so that the longest sequences start first (wkv6_bi)
     int reverse;                      // 1: scan tokens lens-1 .. 0
     const int* rev_n;                 // chunked kernels: per-batch number of leading tokens that the tensors named in rev_mask
     unsigned rev_mask;                //   hold in reverse order (scan position p < rev_n[b] <-> token rev_n[b]-1-p; positions
