@@ -256,6 +256,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read, natural columns (this wave's V tile)
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
         const rsrc_t rs_y = make_rsrc(gy_, (!STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
+        const unsigned nst = (unsigned)(a.T + CKPT_TOK - 1) / CKPT_TOK;          // checkpoint slots of this (batch, head): 16 KB each
+        const rsrc_t rs_ck = make_rsrc(a.ckpt ? a.ckpt + (long)(b * a.H + h) * nst * (HEAD * HEAD) : nullptr, a.ckpt ? nst * 16384u : 0u);
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
             WKV6_T(ts0);
@@ -271,12 +273,14 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 #endif
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
-                if (a.ckpt && (blk * BLK) % a.ckpt_tok == 0 && grp * GRP + blk * BLK < a.T) {   // state every ckpt_tok tokens, for the backward kernel
-                    float* const ck = a.ckpt + ((long)(b * a.H + h) * ((a.T + a.ckpt_tok - 1) / a.ckpt_tok) +
-                                                (grp * GRP + blk * BLK) / a.ckpt_tok) * (HEAD * HEAD);
+                if (a.ckpt && (blk * BLK) % CKPT_TOK == 0) {   // state every CKPT_TOK tokens, for the backward kernel (stages past T: dropped)
+                    const unsigned st = (unsigned)(grp * GRP + blk * BLK) / CKPT_TOK;
 #pragma unroll
-                    for (int it = 0; it < 4; ++it)   // streamed: written once, read once by the backward
-                        __builtin_nontemporal_store(St[it], reinterpret_cast<f4v*>(ck + ((wv * 4 + it) * 64 + lane) * 4));
+                    for (int it = 0; it < 4; ++it) {   // streamed: written once, read once by the backward
+                        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, St[it]), rs_ck,
+                                                               (int)(((st * 16u + wv * 4u + it) * 64u + lane) * 16u), 0, 2 /* slc: streaming */);
+                    }
                 }
                 // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
                 const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);
