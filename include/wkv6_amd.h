@@ -109,14 +109,14 @@ int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, co
 int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                          const void* w, const void* u, const void* s0, void* s_out, void* y,
                          void* ckpt, size_t ckpt_bytes, unsigned flags, void* stream);
-/* gu, gs may be NULL (skipped).  workspace: wkv6_backward_workspace_bytes() bytes, or NULL to use a
- * library-owned grow-only buffer (not safe for concurrent use from several streams). */
+/* gu, gs may be NULL (skipped).  workspace: wkv6_backward_workspace_bytes() bytes, or NULL: the library takes a stream-ordered
+ * allocation on `stream` for the duration of the call (hipMallocAsync / hipFreeAsync; safe from any number of streams). */
 int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                      const void* w, const void* u, const void* s0, const void* gy, void* gr,
                      void* gk, void* gv, void* gw, void* gu, void* gs, void* workspace,
                      size_t workspace_bytes, unsigned flags, void* stream);
 /* lens: int32 [B] device array, number of leading tokens both scans cover (NULL: derive from mask).
- * workspace: wkv6bi_workspace_bytes() bytes (NULL: library-owned buffer). */
+ * workspace: wkv6bi_workspace_bytes() bytes (NULL: stream-ordered allocation for the duration of the call). */
 int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
                       const void* k, const void* v, const void* w, const void* u, void* y,
                       void* workspace, size_t workspace_bytes, unsigned flags, void* stream);

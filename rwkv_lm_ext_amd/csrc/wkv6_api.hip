@@ -23,34 +23,39 @@ int check_shape(int B, int T, int C, int H)
     return WKV6_OK;
 }
 
-// Library-owned scratch for the reference-signature entry points (which have no workspace
-// argument).  Grow-only, one per device, serialised by a mutex; callers that use several streams
-// concurrently must pass their own workspace through the *_ex entry points.
-struct Scratch {
+// Scratch for callers that pass no workspace (the reference-signature entry points have no such argument): a stream-ordered
+// allocation (hipMallocAsync on the caller's stream, hipFreeAsync right behind the launches that use it), so concurrent streams
+// never share a buffer and nothing synchronises the device.  The device's default memory pool is told once to keep what it has
+// been given, which makes the steady state an O(1) pool hit.
+struct StreamScratch {
     void* ptr = nullptr;
-    size_t bytes = 0;
-};
-Scratch g_scratch[16];
-std::mutex g_scratch_mu;
-
-void* internal_scratch(size_t bytes)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
-    Scratch& s = g_scratch[dev];
-    if (s.bytes < bytes) {
-        if (s.ptr) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(s.ptr);
-            s.ptr = nullptr;
-            s.bytes = 0;
+    hipStream_t st = nullptr;
+    void* get(size_t bytes, hipStream_t stream)
+    {
+        static std::mutex mu;
+        static bool tuned[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        if (dev >= 0 && dev < 64) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!tuned[dev]) {
+                hipMemPool_t pool;
+                if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                    unsigned long long keep = ~0ull;
+                    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+                }
+                tuned[dev] = true;
+            }
         }
-        if (hipMalloc(&s.ptr, bytes) != hipSuccess) return nullptr;
-        s.bytes = bytes;
+        st = stream;
+        if (hipMallocAsync(&ptr, bytes, st) != hipSuccess) ptr = nullptr;
+        return ptr;
     }
-    return s.ptr;
-}
+    ~StreamScratch()
+    {
+        if (ptr) (void)hipFreeAsync(ptr, st);
+    }
+};
 
 // lens[b] = 1 + index of the first zero of mask[b][:], or T when the row has no zero
 // (cuda/wkv6_bi_cuda.cu:21-69 breaks AFTER processing the first masked token).
@@ -200,8 +205,9 @@ int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, c
     if (int rc = check_shape(B, T, C, H)) return rc;
     if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw) return WKV6_ENULL;
     const size_t need = wkv6_backward_workspace_bytes(B, T, C, H);
+    StreamScratch scratch;                     // released (stream-ordered) when this call returns
     if (!workspace) {
-        workspace = internal_scratch(need);
+        workspace = scratch.get(need, (hipStream_t)stream);
         if (!workspace) return WKV6_EWORKSPACE;
     } else if (workspace_bytes < need) {
         return WKV6_EWORKSPACE;
@@ -238,8 +244,9 @@ int wkv6_backward_rev_ex(int B, int T, int C, int H, const void* r, const void* 
     if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw || !rev_n) return WKV6_ENULL;
     if ((flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) || (rev_mask & ~(unsigned)REV_ALL)) return WKV6_EUNSUPPORTED;
     const size_t need = wkv6_backward_workspace_bytes(B, T, C, H);
+    StreamScratch scratch;                     // released (stream-ordered) when this call returns
     if (!workspace) {
-        workspace = internal_scratch(need);
+        workspace = scratch.get(need, (hipStream_t)stream);
         if (!workspace) return WKV6_EWORKSPACE;
     } else if (workspace_bytes < need) {
         return WKV6_EWORKSPACE;
@@ -259,8 +266,9 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
     if (!r || !k || !v || !w || !u || !y || (!mask && !lens)) return WKV6_ENULL;
     hipStream_t st = (hipStream_t)stream;
     const size_t need = wkv6bi_workspace_bytes(B, T, C, H);
+    StreamScratch scratch;                     // released (stream-ordered) when this call returns
     if (!workspace) {
-        workspace = internal_scratch(need);
+        workspace = scratch.get(need, (hipStream_t)stream);
         if (!workspace) return WKV6_EWORKSPACE;
     } else if (workspace_bytes < need) {
         return WKV6_EWORKSPACE;
@@ -297,8 +305,9 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
     if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw || (!mask && !lens)) return WKV6_ENULL;
     hipStream_t st = (hipStream_t)stream;
     const size_t need = wkv6bi_workspace_bytes(B, T, C, H);
+    StreamScratch scratch;                     // released (stream-ordered) when this call returns
     if (!workspace) {
-        workspace = internal_scratch(need);
+        workspace = scratch.get(need, (hipStream_t)stream);
         if (!workspace) return WKV6_EWORKSPACE;
     } else if (workspace_bytes < need) {
         return WKV6_EWORKSPACE;
