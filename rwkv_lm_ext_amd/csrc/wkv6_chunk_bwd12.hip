@@ -339,8 +339,6 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         };
         const int qrd = (8 * (4 * (g >> 1)) + 4 * (g & 1) + (x >> 2)) * 16 + (x & 3) * 4;   // read-back: + jt 1024 + q 128
         if (ngrp > 0) request_ckpt(ngrp - 1);
-        const bool plain_stores = !GEN || (!a.accumulate && !a.g_f32[0] && !a.g_f32[1] && !a.g_f32[3]);   // emit = one store, no load
-        int later = 0;
 
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
@@ -349,13 +347,10 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 #endif
             WKV6_T(ts0);
             // stage-entry forward state: read back what this wave requested a stage ago, then request the next one.
-            // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here.  It was issued a whole stage ago,
-            // but this wave's gradient stores of that stage were issued after it and vmcnt retires in order: waiting for
-            // vmcnt(0) would also wait for the acknowledgement of stores issued a few hundred cycles ago.  In plain-store mode a
-            // stage issues exactly six of them (gr, gk, gw of two blocks; on gfx9 vmcnt retires loads and stores in issue order,
-            // which is also what hipcc's own counted waits assume): wait until only those are outstanding.
-            if (later == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here.  It was issued a whole stage ago; the
+            // drain also covers this wave's gradient stores of that stage.  (A counted wait that leaves the six stores outstanding
+            // measured the same -- 0.486 vs 0.488 ms -- and would lean on loads and stores retiring in issue order.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
@@ -397,9 +392,6 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             // the read-back so that the LDS latency of the read-back runs under the rebuild's operand reads and MFMAs.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (grp > 0) request_ckpt(grp - 1);
-#ifndef WKV6_VMCNT0                                                  // (ablation switch: always drain)
-            later = plain_stores ? 6 : 0;   // vector-memory instructions this stage issues after the request (buffer stores: never skipped)
-#endif
             WKV6_T(ts2);
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
