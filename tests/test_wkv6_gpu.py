@@ -445,6 +445,52 @@ def test_chunked_kernels_at_block_and_stage_boundaries(ops, T):
         assert float(np.abs(c - s_).max()) <= (4.0 if n in ("gw", "gu", "gs") else 2.0) * 2.0 ** -8 * scale, (n, T)
 
 
+def test_fuzz_chunked_against_scan_kernels(ops):
+    """Seeded random shapes, lengths and decay regimes: the chunked kernels (plain, with state, wkv6_bi with ragged masks that
+    include one-token and full-length rows) against the exact scan kernels on the device, same inputs, both bf16."""
+    bf = torch.bfloat16
+    rng = np.random.default_rng(2024)
+
+    def agree(tag, names, got, ref):
+        for n, c, s_ in zip(names, got, ref):
+            c, s_ = host(c), host(s_)
+            # gw_t = lw_t (sum of r dq - k dk terms that cancel): for very short sequences the true value is ~0 and what is left
+            # is the 2^-16 operand error of the split-bf16 products times the size of the cancelling terms (O(1..10)), hence
+            # the absolute floor for gw
+            scale = max(float(np.abs(s_).max()), 1e-2 if n == "gw" else 1e-3)
+            assert float(np.abs(c - s_).max()) <= (4.0 if n in ("gw", "gu", "gs") else 2.0) * 2.0 ** -8 * scale, (tag, n)
+
+    for case in range(24):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        T = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 47, 64, 65, 95, 96, 97, 130, 191]))
+        regime = ("init", "stress")[case % 2]
+        r, k, v, w, u, gy = rand_inputs(5000 + case, B, T, H, regime)
+        d = [dev(t, bf) for t in (r, k, v, w, u, gy)]
+        tag = (case, B, T, H, regime)
+        if case % 3 == 2:       # wkv6_bi with ragged masks
+            mask = torch.ones(B, T, dtype=torch.int32)
+            for b in range(B):
+                cut = int(rng.integers(0, T + 1))          # 0: the first token is already masked; T: no zero in the row
+                if cut < T:
+                    mask[b, cut:] = 0
+            m = mask.cuda()
+            yc, ys = ops.bi_forward_ex(m, *d[:5], H), ops.bi_forward_ex(m, *d[:5], H, algo="scan")
+            agree(tag, ("y",), (yc,), (ys,))
+            agree(tag, ("gr", "gk", "gv", "gw", "gu"), ops.bi_backward_ex(m, *d, H), ops.bi_backward_ex(m, *d, H, algo="scan"))
+        else:
+            g = torch.Generator().manual_seed(case)
+            s0 = dev((torch.randn(B, H, 64, 64, generator=g) * 0.5).numpy(), bf) if case % 3 == 1 else None
+            ck = ops.new_checkpoint(B, T, H * 64, H, "cuda")
+            yc = ops.forward_ex(*d[:5], H, s0=s0, ckpt=ck)
+            ys = ops.forward_ex(*d[:5], H, s0=s0, algo="scan")
+            agree(tag, ("y",), (yc,), (ys,))
+            names = ("gr", "gk", "gv", "gw", "gu", "gs")
+            oc = ops.backward_ex(*d, H, s0=s0, want_gs=s0 is not None, ckpt=ck)
+            osn = ops.backward_ex(*d, H, s0=s0, want_gs=s0 is not None, algo="scan")
+            n = 6 if s0 is not None else 5
+            agree(tag, names[:n], oc[:n], osn[:n])
+
+
 def test_forward_checkpoints_feed_backward(ops, oracle):
     """Training path: forward_ex(ckpt=) stores the per-group states, backward_ex(ckpt=) consumes them; results
     must be identical (bitwise) to the self-contained backward that recomputes them with its own state pass."""
