@@ -41,7 +41,7 @@ using namespace chunk;
 constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 
 // STATE_ONLY: no outputs, only the state recurrence (first half of the self-contained backward).
-// With a.ckpt the state is dumped every a.ckpt_tok tokens (fp32, register order:
+// With a.ckpt the state is dumped every CKPT_TOK tokens (fp32, register order:
 // [wave][tile][lane][4]) for the backward kernel.
 // ACC: add into y (from a.y_f32 when given) instead of overwriting -- the reverse half of wkv6_bi.
 template <bool W_RAW, bool STATE_ONLY, bool ACC>
@@ -413,7 +413,7 @@ hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
     return raw ? launch_fwd_variant<true, false, false>(a, st) : launch_fwd_variant<false, false, false>(a, st);
 }
 
-// state recurrence only, dumping the group-entry states into a.ckpt (first half of the self-contained backward)
+// state recurrence only, dumping the stage-entry states into a.ckpt (first half of the self-contained backward)
 hipError_t launch_chunk_state_pass(const ScanArgs& a_, hipStream_t st)
 {
     if (!offsets_fit(a_)) return hipErrorInvalidValue;

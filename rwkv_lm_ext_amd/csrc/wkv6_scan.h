@@ -62,7 +62,7 @@ struct ScanArgs {
     void* gs;                         // [B,H,N,N] per-batch dL/dS0, I/O type (null: skip)
     int part_f32;                     // gu and gs are fp32 whatever the I/O type (WKV6_PARTIALS_F32): the caller sums them over the batch
     float* aux;                       // [B,T,C] fp32 scratch carrying a_t from sweep S to sweep G
-    float* ckpt;                      // chunked path: [B*H][ceil(T/64)][4096] fp32 group-entry states (state pass -> backward)
+    float* ckpt;                      // chunked path: [B*H][ceil(T/32)][4096] fp32 stage-entry states (forward / state pass -> backward)
     int ckpt_tok;                     // tokens between checkpoints (CKPT_TOK)
     int ckpt_valid;                   // backward: ckpt was filled by the forward, skip the state pass
     const int* lens;                  // per-batch number of tokens to scan (null: T)
