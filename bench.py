@@ -42,6 +42,17 @@ def measured_traffic(kernel):
         return None
 
 
+def measured_valu_busy(kernel):
+    """VALU utilisation of the kernel from the same committed PMC file (SURVEY.md 8d asks for it beside the bandwidth figure):
+    SQ_ACTIVE_INST_VALU * 4 / (SIMDs * kernel cycles), with GRBM_GUI_ACTIVE summed over the 8 XCDs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_final_pmc.json")) as f:
+            c = json.load(f)["kernels"][kernel]["counters"]
+        return round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3)
+    except Exception:
+        return None
+
+
 def synth(B, T, H, device, seed=0):
     """SURVEY.md 8d synthetic inputs: r,k,v ~ N(0,1)*0.5, w = model decay-init ramp + N(0,0.1^2), u ~ N(0,0.3^2)."""
     C = H * 64
@@ -281,7 +292,9 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBPS, 4),
                          "traffic": measured_traffic("chunk_bwd12_kernel" if dom_name == "backward" else "chunk_fwd_kernel")
                          if args.workload == "wkv6" else None,
-                         "algorithmic_bytes_per_launch": units * dom_b, "avg_ms": round(dom_ms, 4)},
+                         "algorithmic_bytes_per_launch": units * dom_b, "avg_ms": round(dom_ms, 4),
+                         "valu_busy": measured_valu_busy("chunk_bwd12_kernel" if dom_name == "backward" else "chunk_fwd_kernel")
+                         if args.workload == "wkv6" else None},
             "roofline_step": {"bound": "hbm", "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(step_ach / HBM_PEAK_GBPS, 4),
                               "algorithmic_bytes": units * (FWD_BYTES + BWD_BYTES)},
