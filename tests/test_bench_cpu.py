@@ -1,0 +1,38 @@
+"""bench.py host logic that needs no GPU: the committed PMC figures it reports and the algorithmic-byte bookkeeping
+(10 B forward + 18 B backward per token-channel; config 2 = 1.879 GB per step)."""
+import json
+import os
+
+import bench
+
+
+def test_algorithmic_bytes():
+    assert (bench.FWD_BYTES, bench.BWD_BYTES) == (10, 18)
+    units = 8 * 4096 * 2048
+    assert units * (bench.FWD_BYTES + bench.BWD_BYTES) == 1_879_048_192
+    assert bench.HBM_PEAK_GBPS == 8000.0
+
+
+def test_committed_pmc_figures_are_consistent():
+    bwd, fwd = bench.measured_traffic("chunk_bwd12_kernel"), bench.measured_traffic("chunk_fwd_kernel")
+    units = 8 * 4096 * 2048
+    ckpt = units * 8                                   # one fp32 64x64 state per 32 tokens and head = 8 B per token-channel
+    # measured traffic = algorithmic bytes + checkpoints, within 1 % (no re-reads)
+    assert abs(bwd - (units * 18 + ckpt)) <= 0.01 * bwd
+    assert abs(fwd - (units * 10 + ckpt)) <= 0.01 * fwd
+    for k in ("chunk_bwd12_kernel", "chunk_fwd_kernel"):
+        assert 0.2 < bench.measured_valu_busy(k) < 1.0
+    assert bench.measured_traffic("no_such_kernel") is None
+
+
+def test_committed_bench_lines_carry_the_contract_fields():
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    for name in ("r02_bench_final.json", "r02_bench_bi.json", "r02_bench_infctx.json"):
+        with open(os.path.join(root, "profiles", name)) as f:
+            d = json.loads(f.read())
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in d, (name, key)
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert "workload" in d["config"] and "model" not in d["config"]
