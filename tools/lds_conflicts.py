@@ -90,6 +90,30 @@ def sites_bwd12():
     return out
 
 
+def sites_fwd():
+    out = []
+    x = lambda l: l & 15
+    g = lambda l: l >> 4
+    c4 = lambda l: l & 15
+    tq = lambda l: l >> 4
+    for wv in range(4):
+        out.append((f"consumer tr_read V own tile (troff + 32 wv), wv={wv}", "ds_read_b64_tr_b16",
+                    lambda l, wv=wv: (4 * g(l) + (x(l) >> 2)) * RSB + 8 * (x(l) & 3) + 32 * wv))
+    for it in range(4):
+        out.append((f"consumer tr_read Khat labelled tile (trow + tile_tr({it}))", "ds_read_b64_tr_b16",
+                    lambda l, it=it: (4 * g(l) + (x(l) >> 2)) * RSB + 16 * (x(l) & 3) + tile_tr(it)))
+    for s_ in range(2):
+        out.append((f"consumer / producer row read b8 (x RSB + (32 s + 8 g) 2), s={s_}", "ds_read_b128",
+                    lambda l, s_=s_: x(l) * RSB + (32 * s_ + 8 * g(l)) * 2))
+    out.append(("consumer score fragment (lane 16)", "ds_read_b128", lambda l: l * 16))
+    out.append(("consumer E8 / E16 / E16M8 float4 ((32 s + 8 g) 4)", "ds_read_b128", lambda l: 8 * g(l) * 4))
+    for tt in range(4):
+        out.append((f"producer bf16 row store ((4 tq + tt) RSB + 8 c4), tt={tt}", "ds_write_b64",
+                    lambda l, tt=tt: (4 * tq(l) + tt) * RSB + 8 * c4(l)))
+    out.append(("producer score fragment store (lane 16)", "ds_write_b128", lambda l: l * 16))
+    return out
+
+
 def report(name, sites):
     print(name)
     worst = 0
@@ -103,4 +127,5 @@ def report(name, sites):
 
 if __name__ == "__main__":
     report("chunk_bwd12_kernel", sites_bwd12())
+    report("chunk_fwd_kernel", sites_fwd())
     sys.exit(0)
