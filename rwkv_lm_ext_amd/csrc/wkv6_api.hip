@@ -92,11 +92,83 @@ __global__ void length_order_kernel(const int* __restrict__ lens, int* __restric
 
 int to_rc(hipError_t e) { return e == hipSuccess ? WKV6_OK : (int)e; }
 
+// ---- forward over few, long sequences (inference prefill: B*H << CUs): two-level scan over T.  The sequence is cut into S
+// segments that run as S times as many workgroups:
+//   1. state pass per segment from a zero state: A_seg = the segment's own contribution to the state, and the per-channel sum
+//      of its log-decays (ScanArgs::dsum);
+//   2. one small kernel chains the segments:  S_in(seg+1) = 2^{dsum_seg} (.) S_in(seg) + A_seg  (the recurrence of
+//      cuda/wkv6_cuda.cu:44-57 applied to whole segments), giving every segment its entry state and the final state;
+//   3. the ordinary forward per segment from its entry state.
+// 1.7x the work of one pass at S times the parallelism.  Forward only (no checkpoints: the backward walks whole sequences).
+__global__ void tsplit_combine_kernel(const void* s0, int s_f32, long s0_bstride, const float* __restrict__ A,
+                                      const float* __restrict__ dsum, float* __restrict__ Sin, void* s_out, int H, int S)
+{
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    for (int m = 0; m < HEAD * HEAD / 256; ++m) {
+        const int e = threadIdx.x + 256 * m, i = e & (HEAD - 1);       // state layout [j][i]: i = key channel
+        float cur = 0.f;
+        if (s0) {
+            const long o = (long)b * s0_bstride + (long)h * HEAD * HEAD + e;
+            cur = s_f32 ? reinterpret_cast<const float*>(s0)[o] : bf_lo((uint32_t)reinterpret_cast<const bf16_t*>(s0)[o]);
+        }
+        for (int seg = 0; seg < S; ++seg) {
+            const long bp = ((long)b * S + seg) * H + h;
+            Sin[bp * HEAD * HEAD + e] = cur;
+            float dl = 0.f;
+            for (int q = 0; q < 4; ++q) dl += dsum[(bp * 4 + q) * HEAD + i];
+            cur = fmaf(__builtin_amdgcn_exp2f(dl), cur, A[bp * HEAD * HEAD + e]);
+        }
+        if (s_out) {
+            const long o = ((long)b * H + h) * HEAD * HEAD + e;
+            if (s_f32) reinterpret_cast<float*>(s_out)[o] = cur;
+            else reinterpret_cast<bf16_t*>(s_out)[o] = (bf16_t)(pack_bf2(cur, 0.f) & 0xffffu);
+        }
+    }
+}
+
+int tsplit_segments(const ScanArgs& a)
+{
+    if (a.ckpt || a.lens || a.reverse || a.rev_n || a.order || a.accumulate || a.y_f32 || a.zero_tail || a.dsum) return 1;
+    int want = 0;
+    if (const char* e = getenv("WKV6_TSPLIT")) {       // A/B switch: 0 / 1 = off, n = exactly n segments (if T divides)
+        want = atoi(e);
+        if (want <= 1) return 1;
+        return a.T % (64 * want) == 0 ? want : 1;
+    }
+    const int cus = cu_count();
+    int S = 1;
+    while (2 * S <= 16 && (long)a.B * a.H * 2 * S <= cus && a.T % (64 * 2 * S) == 0 && a.T / (2 * S) >= 512) S *= 2;
+    return S >= 4 ? S : 1;      // two segments do not pay for the extra state pass (two workgroups per pair serve that case)
+}
+
+hipError_t chunk_forward(const ScanArgs& a, hipStream_t st)
+{
+    const int S = tsplit_segments(a);
+    if (S <= 1) return launch_chunk_fwd(a, st);
+    const size_t nstate = (size_t)a.B * S * a.H * HEAD * HEAD;                 // floats
+    const size_t ndsum = (size_t)a.B * S * a.H * 4 * HEAD;
+    StreamScratch scratch;
+    float* const buf = reinterpret_cast<float*>(scratch.get((2 * nstate + ndsum) * sizeof(float), st));
+    if (!buf) return hipErrorOutOfMemory;
+    float* const A = buf, * const Sin = buf + nstate, * const dsum = buf + 2 * nstate;
+    ScanArgs p = a;
+    p.B = a.B * S; p.T = a.T / S;
+    p.s0 = nullptr; p.s0_bstride = 0; p.s_out = A; p.state_f32 = 1; p.y = nullptr; p.dsum = dsum;
+    if (hipError_t e = launch_chunk_state_pass(p, st)) return e;
+    hipLaunchKernelGGL(tsplit_combine_kernel, dim3(a.B * a.H), dim3(256), 0, st, a.s0, a.state_f32, a.s0_bstride, A, dsum, Sin,
+                       a.s_out, a.H, S);
+    if (hipError_t e = hipGetLastError()) return e;
+    p = a;
+    p.B = a.B * S; p.T = a.T / S;
+    p.s0 = Sin; p.s0_bstride = (long)a.H * HEAD * HEAD; p.state_f32 = 1; p.s_out = nullptr;
+    return launch_chunk_fwd(p, st);
+}
+
 // forward dispatch: chunked MFMA kernel for bf16 I/O unless the caller forces the exact scan
 hipError_t run_fwd(const ScanArgs& a, unsigned flags, hipStream_t st)
 {
     if ((flags & WKV6_IO_F32) || (flags & WKV6_ALGO_SCAN)) return launch_scan_fwd(a, flags & WKV6_IO_F32, st);
-    return launch_chunk_fwd(a, st);
+    return chunk_forward(a, st);
 }
 
 hipError_t run_bwd(ScanArgs& a, unsigned flags, float* scratch, hipStream_t st)
@@ -402,7 +474,7 @@ static int rwkv6_infer(int B, int T, int C, int H, float* state, const void* r, 
     a.y = y;
     // prefill-sized calls in bf16 go through the chunked MFMA kernel (log of the given decay, fp32 state I/O); decode
     // (a few tokens) and fp32 I/O use the exact scan
-    if (!f32 && T >= 32) return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
+    if (!f32 && T >= 32) return to_rc(chunk_forward(a, (hipStream_t)stream));
     return to_rc(launch_scan_fwd(a, f32, (hipStream_t)stream));
 }
 int rwkv6_cuda_forward_bf16(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,

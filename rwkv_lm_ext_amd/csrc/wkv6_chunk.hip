@@ -79,6 +79,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 4 * c4, uu);
         uint2 pr[4], pk[4], pv[4], pw[4];
         float4 pe[4];
+        float dtot[4] = {0.f, 0.f, 0.f, 0.f};                            // log2-decay summed over this wave's blocks (a.dsum)
         // buffer resources over this row's first ntok tokens: loads of tokens past the end return 0 without a branch
         const unsigned span = ntok > 0 ? (unsigned)(ntok - 1) * a.C : 0u;     // elements up to the last token's head slice
         const rsrc_t rs_r = make_rsrc(gr_, ntok > 0 ? span * 2 + 128 : 0), rs_k = make_rsrc(gk_, ntok > 0 ? span * 2 + 128 : 0);
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                 pre[c] = inc - cs[3][c];                                 // decay accumulated before this lane's tokens
                 c8[c] = __shfl(pre[c], 32 + c4);                         // ... before token 8
                 c16[c] = __shfl(inc, 48 + c4);                           // whole block
+                dtot[c] += c16[c];                                       // ... and over all the blocks this wave prepares
             }
             if (tq == 0) {
                 *reinterpret_cast<float4*>(bb + OFF_E8 + 16 * c4) =
@@ -238,6 +240,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             WKV6_T(ts4);
             WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3);
         }
+        if (a.dsum && tq == 0 && part == 0)
+            *reinterpret_cast<float4*>(a.dsum + ((long)(b * a.H + h) * 4 + wv) * HEAD + 4 * c4) = make_float4(dtot[0], dtot[1], dtot[2], dtot[3]);
     } else {
         // ============================== consumer: value columns [16wv, 16wv+16) =========================
         // lane (x = lane&15, g = lane>>4) holds S[i = tile_ch(it) + 8g + q][j = 16wv + x] in St[it][q]

@@ -732,7 +732,7 @@ template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStre
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // wkv6_chunk.hip
 
 // two workgroups per (batch, head) when one each would leave at least half of the CUs without work
-int want_split(int BH)
+int cu_count()              // compute units of the current device (0: unknown)
 {
     static int cus[16] = {};
     int dev = 0;
@@ -742,8 +742,12 @@ int want_split(int BH)
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         cus[dev] = prop.multiProcessorCount;
     }
+    return cus[dev];
+}
+int want_split(int BH)
+{
     if (const char* e = getenv("WKV6_SPLIT")) return atoi(e) != 0;     // A/B switch
-    return 2 * BH <= cus[dev];
+    return 2 * BH <= cu_count();
 }
 
 hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)

@@ -75,6 +75,8 @@ struct ScanArgs {
     int use_u;                        // 0: bonus u treated as 0 (reverse half of wkv6_bi)
     int accumulate;                   // 1: add into y / gr,gk,gv,gw instead of overwriting
     int zero_tail;                    // 1: write zeros for tokens >= lens[b]
+    float* dsum;                      // chunked forward / state pass: [B*H][4][64] per-block-slot sums of the (clamped) log2-decays
+                                      // over the whole sequence (the segment summaries of the T-split forward), or null
     int split;                        // chunked kernels, set by the launcher when B*H leaves half the chip idle: two workgroups per
                                       // (batch, head), each with its own producers and half of the consuming waves
 };
@@ -102,5 +104,7 @@ hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st);
 // chunked MFMA backward (bf16 I/O only): state pass + reverse pass; a.ckpt must hold chunk_ckpt_floats() floats
 hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st);
 size_t chunk_ckpt_floats(int B, int T, int H);
+hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // state recurrence only (s_out, ckpt, dsum)
+int cu_count();
 
 }  // namespace wkv6

@@ -264,6 +264,43 @@ def test_two_workgroups_per_head_is_the_same_arithmetic(ops, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("segments", [2, 4, 8])
+def test_two_level_scan_forward_for_few_long_sequences(ops, oracle, monkeypatch, segments):
+    """Forward-only calls on few long sequences are cut into segments that run as extra workgroups (state pass per segment, a
+    chaining kernel, then the ordinary forward from each segment's entry state; wkv6_api.hip: chunk_forward).  WKV6_TSPLIT forces
+    the segment count: y and the final state against the oracle (bf16 contract) and against the one-pass kernel (1 ulp)."""
+    bf = torch.bfloat16
+    B, T, H = 1, 1024, 2
+    r, k, v, w, u, _ = rand_inputs(77, B, T, H, "init")
+    g = torch.Generator().manual_seed(5)
+    s0 = (torch.randn(B, H, 64, 64, generator=g) * 0.5).to(bf).float().numpy()
+    d = [dev(x, bf) for x in (r, k, v, w, u)]
+    out = {}
+    for split in (0, segments):
+        monkeypatch.setenv("WKV6_TSPLIT", str(split))
+        s_out = torch.empty(B, H, 64, 64, device="cuda", dtype=bf)
+        out[split] = (ops.forward_ex(*d, H, s0=dev(s0, bf), s_out=s_out), s_out)
+    yo, so = oracle.forward(r, k, v, w, u, s0, return_state=True)
+    check(out[segments][0], yo, bf, f"{segments}-segment forward y")
+    check(out[segments][1], so, bf, f"{segments}-segment forward final state")
+    for a, b, n in ((out[0][0], out[segments][0], "y"), (out[0][1], out[segments][1], "state")):
+        a, b = host(a), host(b)
+        assert float(np.abs(a - b).max()) <= 2.0 ** -8 * float(np.abs(a).max()), n
+    # the stateful inference operator (fp32 state in place, decay given as exp(-exp(w))) takes the same path for a prefill
+    from rwkv_lm_ext_amd.wkv6_op import rwkv6
+    decay = torch.exp(-torch.exp(torch.from_numpy(w))).cuda().contiguous()
+    res = []
+    for split in (0, segments):
+        monkeypatch.setenv("WKV6_TSPLIT", str(split))
+        state = torch.from_numpy(s0).cuda().contiguous()
+        y = torch.empty(B, T, 64 * H, device="cuda", dtype=bf)
+        rwkv6.forward_bf16(B, T, 64 * H, H, state, d[0], d[1], d[2], decay, d[4], y)
+        res.append((y, state))
+    check(res[1][0], yo, bf, "rwkv6 prefill y")
+    assert max_norm_err(host(res[1][1]), so) <= 1e-3
+    assert float((res[0][0].float() - res[1][0].float()).abs().max()) <= 2.0 ** -8 * float(res[0][0].float().abs().max())
+
+
 def test_checkpoint_opt_out_gives_identical_gradients(ops, monkeypatch):
     """RWKV_AMD_NO_CKPT=1: nothing is kept from forward to backward, the backward rebuilds the state checkpoints itself --
     same kernels on the same numbers, so every gradient is bit-identical (WKV_6 and WKV_6_BI)."""

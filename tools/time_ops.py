@@ -17,6 +17,7 @@ ap.add_argument("--T", type=int, default=4096)
 ap.add_argument("--H", type=int, default=32)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--only", default="both", choices=["both", "fwd", "bwd"])
+ap.add_argument("--no-ckpt", action="store_true", help="forward without checkpoints (inference-style call)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 B, T, H = args.B, args.T, args.H
@@ -39,7 +40,7 @@ def run(fn, n):
     return e0.elapsed_time(e1) / n
 
 
-fwd = lambda: wkv6_op.forward_ex(r, k, v, w, u, H, y=y, ckpt=ckpt)
+fwd = lambda: wkv6_op.forward_ex(r, k, v, w, u, H, y=y, ckpt=None if args.no_ckpt else ckpt)
 bwd = lambda: wkv6_op.backward_ex(r, k, v, w, u, gy, H, ckpt=ckpt)
 for _ in range(30):
     fwd()
