@@ -99,7 +99,8 @@ int to_rc(hipError_t e) { return e == hipSuccess ? WKV6_OK : (int)e; }
 //   2. one small kernel chains the segments:  S_in(seg+1) = 2^{dsum_seg} (.) S_in(seg) + A_seg  (the recurrence of
 //      cuda/wkv6_cuda.cu:44-57 applied to whole segments), giving every segment its entry state and the final state;
 //   3. the ordinary forward per segment from its entry state.
-// 1.7x the work of one pass at S times the parallelism.  Forward only (no checkpoints: the backward walks whole sequences).
+// 1.7x the work of one pass at S times the parallelism.  The backward still walks whole sequences; the forward's checkpoints
+// for it keep their whole-sequence layout (ScanArgs::ckpt_segs).
 __global__ void tsplit_combine_kernel(const void* s0, int s_f32, long s0_bstride, const float* __restrict__ A,
                                       const float* __restrict__ dsum, float* __restrict__ Sin, void* s_out, int H, int S)
 {
@@ -128,7 +129,7 @@ __global__ void tsplit_combine_kernel(const void* s0, int s_f32, long s0_bstride
 
 int tsplit_segments(const ScanArgs& a)
 {
-    if (a.ckpt || a.lens || a.reverse || a.rev_n || a.order || a.accumulate || a.y_f32 || a.zero_tail || a.dsum) return 1;
+    if (a.lens || a.reverse || a.rev_n || a.order || a.accumulate || a.y_f32 || a.zero_tail || a.dsum) return 1;
     int want = 0;
     if (const char* e = getenv("WKV6_TSPLIT")) {       // A/B switch: 0 / 1 = off, n = exactly n segments (if T divides)
         want = atoi(e);
@@ -153,7 +154,7 @@ hipError_t chunk_forward(const ScanArgs& a, hipStream_t st)
     float* const A = buf, * const Sin = buf + nstate, * const dsum = buf + 2 * nstate;
     ScanArgs p = a;
     p.B = a.B * S; p.T = a.T / S;
-    p.s0 = nullptr; p.s0_bstride = 0; p.s_out = A; p.state_f32 = 1; p.y = nullptr; p.dsum = dsum;
+    p.s0 = nullptr; p.s0_bstride = 0; p.s_out = A; p.state_f32 = 1; p.y = nullptr; p.dsum = dsum; p.ckpt = nullptr;
     if (hipError_t e = launch_chunk_state_pass(p, st)) return e;
     hipLaunchKernelGGL(tsplit_combine_kernel, dim3(a.B * a.H), dim3(256), 0, st, a.s0, a.state_f32, a.s0_bstride, A, dsum, Sin,
                        a.s_out, a.H, S);
@@ -161,6 +162,7 @@ hipError_t chunk_forward(const ScanArgs& a, hipStream_t st)
     p = a;
     p.B = a.B * S; p.T = a.T / S;
     p.s0 = Sin; p.s0_bstride = (long)a.H * HEAD * HEAD; p.state_f32 = 1; p.s_out = nullptr;
+    p.ckpt_segs = S;                               // checkpoints (training forward) land in the whole sequences' slots
     return launch_chunk_fwd(p, st);
 }
 
@@ -266,7 +268,7 @@ int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* 
     a.s_out = s_out;
     a.y = y;
     a.ckpt = reinterpret_cast<float*>(ckpt);
-    return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
+    return to_rc(chunk_forward(a, (hipStream_t)stream));
 }
 
 int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,

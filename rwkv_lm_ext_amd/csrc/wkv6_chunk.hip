@@ -261,7 +261,11 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
         const rsrc_t rs_y = make_rsrc(gy_, (!STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
         const unsigned nst = (unsigned)(a.T + CKPT_TOK - 1) / CKPT_TOK;          // checkpoint slots of this (batch, head): 16 KB each
-        const rsrc_t rs_ck = make_rsrc(a.ckpt ? a.ckpt + (long)(b * a.H + h) * nst * (HEAD * HEAD) : nullptr, a.ckpt ? nst * 16384u : 0u);
+        // (two-level scan: this batch row is segment b % S of sequence b / S; the S segments' slots are consecutive, which is the
+        // whole sequence's ordinary checkpoint layout)
+        const int segs = a.ckpt_segs > 1 ? a.ckpt_segs : 1;
+        const long ck_slot0 = ((long)((b / segs) * a.H + h) * segs + b % segs) * nst;
+        const rsrc_t rs_ck = make_rsrc(a.ckpt ? a.ckpt + ck_slot0 * (HEAD * HEAD) : nullptr, a.ckpt ? nst * 16384u : 0u);
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
             WKV6_T(ts0);

@@ -75,6 +75,8 @@ struct ScanArgs {
     int use_u;                        // 0: bonus u treated as 0 (reverse half of wkv6_bi)
     int accumulate;                   // 1: add into y / gr,gk,gv,gw instead of overwriting
     int zero_tail;                    // 1: write zeros for tokens >= lens[b]
+    int ckpt_segs;                    // chunked forward as a two-level scan: batch row b is segment b % ckpt_segs of sequence
+                                      // b / ckpt_segs, and its checkpoints go to that sequence's slots (0 / 1: plain)
     float* dsum;                      // chunked forward / state pass: [B*H][4][64] per-block-slot sums of the (clamped) log2-decays
                                       // over the whole sequence (the segment summaries of the T-split forward), or null
     int split;                        // chunked kernels, set by the launcher when B*H leaves half the chip idle: two workgroups per

@@ -286,6 +286,16 @@ def test_two_level_scan_forward_for_few_long_sequences(ops, oracle, monkeypatch,
     for a, b, n in ((out[0][0], out[segments][0], "y"), (out[0][1], out[segments][1], "state")):
         a, b = host(a), host(b)
         assert float(np.abs(a - b).max()) <= 2.0 ** -8 * float(np.abs(a).max()), n
+    # training forward: the segments' checkpoints land in the whole sequence's slots and feed the ordinary backward
+    monkeypatch.setenv("WKV6_TSPLIT", str(segments))
+    gy = rand_inputs(78, B, T, H, "init")[5]
+    ck = ops.new_checkpoint(B, T, 64 * H, H, "cuda")
+    y_ck = ops.forward_ex(*d, H, s0=dev(s0, bf), ckpt=ck)
+    assert torch.equal(y_ck, out[segments][0])
+    grads = ops.backward_ex(*d, dev(gy, bf), H, s0=dev(s0, bf), want_gs=True, ckpt=ck)
+    og = oracle.backward(r, k, v, w, u, gy, s0)
+    for n, t in zip(("gr", "gk", "gv", "gw"), grads[:4]):
+        check(t, og[n], bf, f"{segments}-segment forward checkpoints -> backward {n}")
     # the stateful inference operator (fp32 state in place, decay given as exp(-exp(w))) takes the same path for a prefill
     from rwkv_lm_ext_amd.wkv6_op import rwkv6
     decay = torch.exp(-torch.exp(torch.from_numpy(w))).cuda().contiguous()
