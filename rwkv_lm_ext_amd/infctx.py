@@ -6,7 +6,6 @@ src/model.py:738-812: token shift starts from the previous chunk's last token, t
 state and hands the final state on (RUN_CUDA_RWKV6_STATE of the 'infctx' flavour, src/model.py:130-132).
 """
 import torch
-import torch.nn.functional as F
 
 
 class TimeMixState:

@@ -7,7 +7,7 @@ forward and backward are one HIP kernel each; parameter gradients come back as f
 import torch
 
 from . import _lib
-from .wkv6_op import _check_tensors, _ptr, _stream_ptr   # noqa: F401  (same validation / stream conventions)
+from .wkv6_op import _ptr, _stream_ptr                   # same pointer / stream conventions as the operator
 
 _NPARTS = 1024
 
