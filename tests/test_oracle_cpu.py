@@ -154,3 +154,21 @@ def test_python_operator_rejects_cpu_and_wrong_dtype_tensors():
         WKV_6_BI.apply(B, T, C, H, torch.ones(B, T, dtype=torch.int64), x, x, x, x, u)
     assert hasattr(torch.ops.wkv6, "forward") and hasattr(torch.ops.wkv6bi, "backward")
     assert hasattr(torch.ops.wkv6state, "forward") and hasattr(torch.ops.wkv6infctx, "backward")
+
+
+def test_python_constants_match_the_header():
+    """The ctypes layer mirrors the header's enums by value: keep them from drifting apart."""
+    import os
+    import re
+    from rwkv_lm_ext_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "include", "wkv6_amd.h")) as f:
+        text = f.read()
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(WKV6_[A-Z0-9_]+)\s*=\s*(-?\d+)", text)}
+    pairs = dict(WKV6_W_EW_F32=_lib.W_EW_F32, WKV6_W_RAW=_lib.W_RAW, WKV6_IO_F32=_lib.IO_F32, WKV6_S0_PER_BATCH=_lib.S0_PER_BATCH,
+                 WKV6_ALGO_SCAN=_lib.ALGO_SCAN, WKV6_CKPT_VALID=_lib.CKPT_VALID, WKV6_BI_KEEP_CKPT=_lib.BI_KEEP_CKPT,
+                 WKV6_PARTIALS_F32=_lib.PARTIALS_F32, WKV6_REV_R=_lib.REV_R, WKV6_REV_K=_lib.REV_K, WKV6_REV_V=_lib.REV_V,
+                 WKV6_REV_W=_lib.REV_W, WKV6_REV_Y=_lib.REV_Y)
+    for name, value in pairs.items():
+        assert enums[name] == value, name
+    assert _lib.REV_ALL == _lib.REV_R | _lib.REV_K | _lib.REV_V | _lib.REV_W | _lib.REV_Y
