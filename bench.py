@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """WKV6 fwd+bwd micro-benchmark on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wkv6|infctx|bi|dp_lora] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wkv6|infctx|bi|dp_lora|prefill] [--no-cpu]
 
 One "step" = one forward + one backward of the WKV6 operator through the C ABI of librwkv6_amd.so on one
 batch of synthetic bf16 inputs that already live in HBM (BASELINE.json configs[1]: B=8, T=4096, C=2048,
@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="wkv6", choices=["wkv6", "infctx", "bi", "dp_lora"])
+    ap.add_argument("--workload", default="wkv6", choices=["wkv6", "infctx", "bi", "dp_lora", "prefill"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--layers", type=int, default=24, help="dp_lora: number of RWKV blocks (1B6: 24)")
     ap.add_argument("--per-gpu-batch", type=int, default=32, help="dp_lora: triples per GPU and step")
@@ -194,6 +194,9 @@ def main():
     if args.workload == "wkv6":
         B, T, H = 8, 4096, 32
         name = "wkv6_fwd_bwd B=8 T=4096 C=2048 H=32 (BASELINE configs[1])"
+    elif args.workload == "prefill":
+        B, T, H = 1, 16384, 32
+        name = "WKV6 forward only (inference prefill) B=1 T=16384 C=2048, two-level scan over T; not a BASELINE config"
     elif args.workload == "infctx":
         B, T, H = 4, 16384, 32
         name = "wkv6infctx fwd+bwd B=4 T=16384 in 8 chunks of 2048, bf16 state carry (BASELINE configs[4])"
@@ -213,6 +216,14 @@ def main():
 
         def bwd():
             wkv6_op.backward_ex(r, k, v, w, u, gy, H, ckpt=ckpt)
+    elif args.workload == "prefill":
+        y = torch.empty_like(r)
+
+        def fwd():
+            wkv6_op.forward_ex(r, k, v, w, u, H, y=y)
+
+        def bwd():
+            pass
     elif args.workload == "infctx":
         chunks = [slice(2048 * c, 2048 * (c + 1)) for c in range(8)]
         parts = [[x[:, sl].contiguous() for x in (r, k, v, w, gy)] for sl in chunks]
@@ -273,9 +284,11 @@ def main():
         units = tokens * C                                    # token-channels per step per GPU
         dom_name, dom_ms, dom_b = ("backward", bwd_ms, BWD_BYTES) if bwd_ms >= fwd_ms else ("forward", fwd_ms, FWD_BYTES)
         ach = units * dom_b / (dom_ms * 1e-3) / 1e9
-        step_ach = units * (FWD_BYTES + BWD_BYTES) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
+        step_bytes = FWD_BYTES if args.workload == "prefill" else FWD_BYTES + BWD_BYTES
+        step_ach = units * step_bytes / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
         out = {
-            "metric": "WKV6 fwd+bwd tokens/sec/GPU (B=8,T=4096,C=2048) + %HBM roofline",
+            "metric": "WKV6 forward tokens/sec/GPU (inference prefill)" if args.workload == "prefill"
+            else "WKV6 fwd+bwd tokens/sec/GPU (B=8,T=4096,C=2048) + %HBM roofline",
             "value": round(world * tokens * args.steps / elapsed, 1),
             "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_iters": PREWARM,
@@ -297,7 +310,7 @@ def main():
                          if args.workload == "wkv6" else None},
             "roofline_step": {"bound": "hbm", "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(step_ach / HBM_PEAK_GBPS, 4),
-                              "algorithmic_bytes": units * (FWD_BYTES + BWD_BYTES)},
+                              "algorithmic_bytes": units * step_bytes},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
