@@ -199,7 +199,7 @@ ScanArgs base_args(int B, int T, int C, int H, const void* r, const void* k, con
 
 }  // namespace
 
-#ifdef WKV6_STAMP
+#if defined(WKV6_STAMP) || defined(WKV6_CLOCK)
 namespace wkv6 { unsigned long long* g_stamp_buffer = nullptr; }
 extern "C" void wkv6_set_debug_buffer(void* p) { wkv6::g_stamp_buffer = reinterpret_cast<unsigned long long*>(p); }
 #endif

@@ -4,11 +4,17 @@
 
 // Diagnostic build (-DWKV6_STAMP, tools/ablate.sh): waves accumulate s_memtime cycles per phase into the buffer set through
 // wkv6_set_debug_buffer(); no stamp executes in the normal build.
+// -DWKV6_CLOCK: only one (s_memtime, s_memrealtime) pair around each wave's whole life, slots 6 / 7 of its record: the in-kernel
+// shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz with no per-phase stamp in the loop (tools/clock_probe.py).
+#if defined(WKV6_STAMP) || defined(WKV6_CLOCK)
+#define WKV6_DEBUGBUF 1
+#define WKV6_CLK(c, r) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r) :: "memory")
+namespace wkv6 { extern unsigned long long* g_stamp_buffer; }
+#endif
 #ifdef WKV6_STAMP
 #define WKV6_T(var) do { __builtin_amdgcn_sched_barrier(0); \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define WKV6_ACC(k, t1, t0) stamp_acc[k] += (t1) - (t0)
-namespace wkv6 { extern unsigned long long* g_stamp_buffer; }
 #else
 #define WKV6_T(var) do { } while (0)
 #define WKV6_ACC(k, t1, t0) do { } while (0)

@@ -71,6 +71,10 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 #ifdef WKV6_STAMP
     unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
 #endif
+#ifdef WKV6_DEBUGBUF
+    unsigned long long clk0 = 0, rtc0 = 0, clk1 = 0, rtc1 = 0;
+    WKV6_CLK(clk0, rtc0);
+#endif
 
     if (producer) {
         // ================================ producer: operands of block wv =================================
@@ -378,10 +382,15 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             }
         }
     }
-#ifdef WKV6_STAMP
+#ifdef WKV6_DEBUGBUF
+    WKV6_CLK(clk1, rtc1);
     if (a.aux && lane == 0) {
         unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)bh * 16 + wid) * 8;
+#ifdef WKV6_STAMP
         for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
+#endif
+        d[6] = clk1 - clk0;
+        d[7] = rtc1 - rtc0;
     }
 #endif
     if (!STATE_ONLY && !ACC && a.zero_tail) {
@@ -413,7 +422,7 @@ hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
     if (!offsets_fit(a_)) return hipErrorInvalidValue;
     ScanArgs a = a_;
     a.split = want_split(a.B * a.H);
-#ifdef WKV6_STAMP
+#ifdef WKV6_DEBUGBUF
     a.aux = reinterpret_cast<float*>(g_stamp_buffer);
 #endif
     const bool raw = a.wkind == 1;          // 0: fp32 ew = -exp(w), 1: raw w in bf16, 2: fp32 decay exp(-exp(w))

@@ -131,6 +131,10 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 #ifdef WKV6_STAMP
     unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
 #endif
+#ifdef WKV6_DEBUGBUF
+    unsigned long long clk0 = 0, rtc0 = 0, clk1 = 0, rtc1 = 0;
+    WKV6_CLK(clk0, rtc0);
+#endif
     // ---- producer role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block pb
     const int c8i = lane & 7, tq = lane >> 3;
     const int ch0 = 32 * half + 4 * c8i;
@@ -693,10 +697,15 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
             }
         }
     }
-#ifdef WKV6_STAMP
+#ifdef WKV6_DEBUGBUF
+    WKV6_CLK(clk1, rtc1);
     if (a.aux && lane == 0) {
         unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)bh * 16 + wid) * 8;
+#ifdef WKV6_STAMP
         for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
+#endif
+        d[6] = clk1 - clk0;
+        d[7] = rtc1 - rtc0;
     }
 #endif
     if (GEN && a.zero_tail && !a.accumulate && part == 0) {
@@ -761,7 +770,7 @@ hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)
         sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
         if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
     }
-#ifdef WKV6_STAMP
+#ifdef WKV6_DEBUGBUF
     ScanArgs b = a;
     b.aux = reinterpret_cast<float*>(g_stamp_buffer);
     return b.wkind ? launch_bwd12_variant<true>(b, st) : launch_bwd12_variant<false>(b, st);
