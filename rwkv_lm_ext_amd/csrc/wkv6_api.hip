@@ -193,7 +193,7 @@ ScanArgs base_args(int B, int T, int C, int H, const void* r, const void* k, con
     a.wkind = (flags & WKV6_W_RAW) ? 1 : 0;
     a.part_f32 = (flags & WKV6_PARTIALS_F32) ? 1 : 0;
     a.use_u = 1;
-    a.ckpt_tok = ckpt_tok();
+    a.ckpt_tok = chunk_ckpt_tok(B * H);
     return a;
 }
 

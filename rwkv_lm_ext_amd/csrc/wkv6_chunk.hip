@@ -41,7 +41,7 @@ using namespace chunk;
 constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 
 // STATE_ONLY: no outputs, only the state recurrence (first half of the self-contained backward).
-// With a.ckpt the state is dumped every CKPT_TOK tokens (fp32, register order:
+// With a.ckpt the state is dumped every a.ckpt_tok tokens (fp32, register order:
 // [wave][tile][lane][4]) for the backward kernel.
 // ACC: add into y (from a.y_f32 when given) instead of overwriting -- the reverse half of wkv6_bi.
 template <bool W_RAW, bool STATE_ONLY, bool ACC>
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read, natural columns (this wave's V tile)
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
         const rsrc_t rs_y = make_rsrc(gy_, (!STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
-        const unsigned nst = (unsigned)(a.T + CKPT_TOK - 1) / CKPT_TOK;          // checkpoint slots of this (batch, head): 16 KB each
+        const unsigned ckt = (unsigned)a.ckpt_tok;                               // 32 (12-wave backward) or 64 (two-level backward)
+        const unsigned nst = ((unsigned)a.T + ckt - 1) / ckt;                    // checkpoint slots of this (batch, head): 16 KB each
         // (two-level scan: this batch row is segment b % S of sequence b / S; the S segments' slots are consecutive, which is the
         // whole sequence's ordinary checkpoint layout)
         const int segs = a.ckpt_segs > 1 ? a.ckpt_segs : 1;
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 #endif
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
-                if (a.ckpt && (blk * BLK) % CKPT_TOK == 0) {   // state every CKPT_TOK tokens, for the backward kernel (stages past T: dropped)
-                    const unsigned st = (unsigned)(grp * GRP + blk * BLK) / CKPT_TOK;
+                if (a.ckpt && (unsigned)(blk * BLK) % ckt == 0) {   // state every ckpt_tok tokens, for the backward kernel (slots past T: dropped)
+                    const unsigned st = (unsigned)(grp * GRP + blk * BLK) / ckt;
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {   // streamed: written once, read once by the backward
                         typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -441,7 +442,8 @@ hipError_t launch_chunk_state_pass(const ScanArgs& a_, hipStream_t st)
 
 size_t chunk_ckpt_floats(int B, int T, int H)
 {
-    return (size_t)B * H * ((T + ckpt_tok() - 1) / ckpt_tok()) * HEAD * HEAD;
+    const int ckt = chunk_ckpt_tok(B * H);
+    return (size_t)B * H * ((T + ckt - 1) / ckt) * HEAD * HEAD;
 }
 
 }  // namespace wkv6

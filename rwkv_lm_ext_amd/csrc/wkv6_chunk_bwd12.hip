@@ -759,17 +759,26 @@ int want_split(int BH)
     return 2 * BH <= cu_count();
 }
 
+// Which chunked backward serves a call with BH (batch, head) pairs, hence how far apart the forward's checkpoints are:
+// the two-level 16-wave kernel (64) unless two workgroups have to share a pair (32).  WKV6_BWD=12 / 64 forces one (A/B switch).
+int chunk_ckpt_tok(int BH)
+{
+    if (const char* e = getenv("WKV6_BWD")) return atoi(e) == 12 ? STG : 64;
+    return want_split(BH) ? STG : 64;
+}
+
 hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)
 {
     ScanArgs a = a_;
-    a.split = want_split(a.B * a.H);
-    if (a.ckpt_tok != STG) return hipErrorInvalidValue;
+    a.split = a.ckpt_tok == STG ? want_split(a.B * a.H) : 0;
+    if (a.ckpt_tok != STG && a.ckpt_tok != 64) return hipErrorInvalidValue;
     if (a.wkind != 1 && ((long)a.T + 64) * a.C >= (1L << 30)) return hipErrorInvalidValue;   // 32-bit byte offsets of the fp32 decay input
     if (!a.ckpt_valid) {                   // self-contained backward: state pass first (same inputs, no outputs)
         ScanArgs sp = a;
         sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
         if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
     }
+    if (a.ckpt_tok == 64) return launch_chunk_bwd64(a, st);
 #ifdef WKV6_DEBUGBUF
     ScanArgs b = a;
     b.aux = reinterpret_cast<float*>(g_stamp_buffer);

@@ -23,10 +23,10 @@
 
 namespace wkv6 {
 
-// The chunked forward leaves an fp32 state checkpoint every ckpt_tok() tokens for the chunked backward
-// (wkv6_chunk_bwd12.hip: one per 32-token stage).
-constexpr int CKPT_TOK = 32;
-inline int ckpt_tok() { return CKPT_TOK; }
+// The chunked forward leaves an fp32 state checkpoint every chunk_ckpt_tok(B*H) tokens for the chunked backward: 64 for the
+// two-level backward (wkv6_chunk_bwd64.hip, one per chunk), 32 for the 12-wave staged backward (wkv6_chunk_bwd12.hip, one per
+// stage), which still serves the calls with so few (batch, head) pairs that two workgroups share one (ScanArgs::split).
+int chunk_ckpt_tok(int BH);                  // wkv6_chunk_bwd12.hip
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute is per device.
 struct LdsAttrOnce {
@@ -63,7 +63,7 @@ struct ScanArgs {
     int part_f32;                     // gu and gs are fp32 whatever the I/O type (WKV6_PARTIALS_F32): the caller sums them over the batch
     float* aux;                       // [B,T,C] fp32 scratch carrying a_t from sweep S to sweep G
     float* ckpt;                      // chunked path: [B*H][ceil(T/32)][4096] fp32 stage-entry states (forward / state pass -> backward)
-    int ckpt_tok;                     // tokens between checkpoints (CKPT_TOK)
+    int ckpt_tok;                     // tokens between checkpoints: chunk_ckpt_tok(B*H)
     int ckpt_valid;                   // backward: ckpt was filled by the forward, skip the state pass
     const int* lens;                  // per-batch number of tokens to scan (null: T)
     const int* order;                 // chunked kernels: batch row served by workgroup slot blockIdx / H (null: identity) -- rows
@@ -105,6 +105,7 @@ hipError_t launch_selftest(int* result, hipStream_t st);
 hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st);
 // chunked MFMA backward (bf16 I/O only): state pass + reverse pass; a.ckpt must hold chunk_ckpt_floats() floats
 hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st);
+hipError_t launch_chunk_bwd64(const ScanArgs& a, hipStream_t st);     // two-level backward proper (wkv6_chunk_bwd64.hip)
 size_t chunk_ckpt_floats(int B, int T, int H);
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // state recurrence only (s_out, ckpt, dsum)
 int cu_count();

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""fp64 numpy emulation of the block algebra of csrc/wkv6_chunk_bwd64.hip (two-level chunking: 64-token chunks, 16-token blocks,
+integer reference frames), checked against the oracle.  Run on CPU: python tools/emulate_bwd64.py
+
+Per chunk (p = position in chunk, I = p >> 4, channel i), log2-decays lw2_p <= 0:
+    C_p   = sum_{q<p} lw2_q          (exclusive, 0 at the chunk start),  P4 = C_64
+    N_I   = rint(C at token 16 I + 8)                                     (integer frame of block I)
+    fR_p  = 2^{C_p - N_I},  fK_p = 2^{N_I - C_{p+1}},  Rhat = r fR,  Khat = k fK        (|exponent| <= 8 tokens + 0.5)
+    pair (a in I, b in J, b < a):   2^{C_a - C_{b+1}} = fR_a 2^{N_I - N_J} fK_b          (power-of-two ratio between frames)
+S = state at chunk entry (checkpoint), G = dL/d(state at chunk exit).
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import wkv6_oracle as orc  # noqa: E402
+
+LW_MIN2 = -9.0 * np.log2(np.e)
+
+
+def backward_head(r, k, v, w, u, gy, s0=None):
+    """r,k,v,w,gy [T,64] float64 (one head), u [64].  Returns gr,gk,gv,gw,gu,gs."""
+    T, N = r.shape
+    lw = -np.exp(w)
+    lw2 = np.maximum(lw * np.log2(np.e), LW_MIN2)
+    nC = (T + 63) // 64
+    Tp = nC * 64
+    pad = lambda a: np.concatenate([a, np.zeros((Tp - T, N))], 0)
+    r_, k_, v_, gy_, lw2_, lw_ = map(pad, (r, k, v, gy, lw2, lw))
+    # forward pass for the chunk-entry states (what the forward kernel checkpoints)
+    S = np.zeros((N, N)) if s0 is None else s0.T.copy()          # S[i][j]; s0 layout [j][i]
+    ckpt = []
+    for c in range(nC):
+        ckpt.append(S.copy())
+        for p in range(64 * c, 64 * c + 64):
+            S = (2.0 ** lw2_[p])[:, None] * S + np.outer(k_[p], v_[p])
+    gr = np.zeros((Tp, N)); gk = np.zeros((Tp, N)); gv = np.zeros((Tp, N)); gw = np.zeros((Tp, N)); gu = np.zeros(N)
+    G = np.zeros((N, N))
+    Rc = np.zeros(N)
+    for c in range(nC - 1, -1, -1):
+        sl = slice(64 * c, 64 * c + 64)
+        rc, kc, vc, gc, l2, lwt = r_[sl], k_[sl], v_[sl], gy_[sl], lw2_[sl], lw_[sl]
+        Cx = np.concatenate([np.zeros((1, N)), np.cumsum(l2, 0)], 0)     # C_0 .. C_64
+        P4 = Cx[64]
+        NI = np.stack([np.rint(Cx[16 * I + 8]) for I in range(4)])       # [4][N]
+        blk = np.arange(64) >> 4
+        fR = 2.0 ** (Cx[:64] - NI[blk])
+        fK = 2.0 ** (NI[blk] - Cx[1:65])
+        Rh, Kh = rc * fR, kc * fK
+        assert np.abs(Cx[:64] - NI[blk]).max() <= 8 * 13 + 0.51
+        S = ckpt[c]
+        NE = np.rint(P4)
+        Gop = (2.0 ** (P4 - NE))[:, None] * G                            # what is published as the MFMA operand
+        vg = (gc * vc).sum(1)
+        cf = (rc * u * kc).sum(1)
+        dq = np.zeros((64, N)); dk = np.zeros((64, N)); gvc = np.zeros((64, N))
+        for I in range(4):
+            a_ = slice(16 * I, 16 * I + 16)
+            # state terms
+            dq[a_] += (2.0 ** NI[I]) * (gc[a_] @ S.T)                    # sum_j S[i][j] gy_a[j]
+            dk[a_] += (2.0 ** (NE - NI[I])) * (vc[a_] @ Gop.T)           # sum_j Gop[i][j] v_b[j]
+            KE = Kh[a_] * 2.0 ** (NE - NI[I])                            # exponent-shifted Khat fragments
+            gvc[a_] += KE @ Gop
+            for J in range(I + 1):
+                b_ = slice(16 * J, 16 * J + 16)
+                D = 2.0 ** (NI[I] - NI[J])
+                dA = gc[a_] @ vc[b_].T                                   # [a][b]
+                sc = (Rh[a_] * D) @ Kh[b_].T                             # scores [a][b], shifted Rhat
+                if I == J:
+                    m = np.tril(np.ones((16, 16)), -1)
+                    dA = dA * m
+                    sc = sc * m + np.diag(cf[a_])
+                dq[a_] += D * (dA @ Kh[b_])
+                dk[b_] += D * (dA.T @ Rh[a_])
+                gvc[b_] += sc.T @ gc[a_]
+        dq *= fR
+        dk *= fK
+        gr[sl] = dq + vg[:, None] * u * kc
+        gk[sl] = dk + vg[:, None] * u * rc
+        gv[sl] = gvc
+        gu += (vg[:, None] * rc * kc).sum(0)
+        dl = rc * dq - kc * dk
+        sfx = np.cumsum(dl[::-1], 0)[::-1]                               # inclusive suffix within the chunk
+        # gw multiplier: the true lw times d_true / d_clamped where the clamp is active (first-order fix-up of the kernels)
+        lwe = lwt * np.exp(np.minimum(lwt + 9.0, 0.0))
+        gw[sl] = lwe * (Rc + (sfx - dl) - kc * dk)
+        Rc = Rc + dl.sum(0)
+        # G at the chunk entry
+        Gn = (2.0 ** P4)[:, None] * G
+        for I in range(4):
+            a_ = slice(16 * I, 16 * I + 16)
+            Gn += (2.0 ** NI[I])[:, None] * (Rh[a_].T @ gc[a_])
+        G = Gn
+    return gr[:T], gk[:T], gv[:T], gw[:T], gu, G.T       # gs layout [j][i]
+
+
+def main():
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for (B, T, H, wlo, whi, with_s0) in [(1, 200, 2, -6, 1, False), (2, 130, 1, -2, 2.3, True), (1, 64, 1, -8, -3, False), (1, 77, 1, 0.5, 2.5, True)]:
+        C = H * 64
+        f32 = np.float32
+        r, k, v, gy = (rng.standard_normal((B, T, C)).astype(f32) * 0.5 for _ in range(4))
+        w = rng.uniform(wlo, whi, (B, T, C)).astype(f32)
+        u = (rng.standard_normal((H, 64)) * 0.3).astype(f32)
+        s0 = (rng.standard_normal((B, H, 64, 64)) * 0.3).astype(f32) if with_s0 else None
+        ref = orc.backward(r, k, v, w, u, gy, s0=s0)
+        for b in range(B):
+            for h in range(H):
+                sl = slice(64 * h, 64 * h + 64)
+                out = backward_head(*(t[b, :, sl].astype(np.float64) for t in (r, k, v, w)), u[h].astype(np.float64),
+                                    gy[b, :, sl].astype(np.float64), None if s0 is None else s0[b, h].astype(np.float64))
+                names = ("gr", "gk", "gv", "gw")
+                for n, o in zip(names, out[:4]):
+                    e = np.abs(o - ref[n][b, :, sl]).max() / max(np.abs(ref[n][b, :, sl]).max(), 1e-30)
+                    worst = max(worst, e)
+                    print(f"B{b} h{h} T{T} w[{wlo},{whi}] {n}: {e:.2e}")
+                e = np.abs(out[4] - ref["gu_b"][b, sl]).max() / np.abs(ref["gu_b"][b, sl]).max()
+                print(f"   gu {e:.2e}")
+                worst = max(worst, e)
+                if s0 is not None:
+                    e = np.abs(out[5] - ref["gs_b"][b, h]).max() / np.abs(ref["gs_b"][b, h]).max()
+                    print(f"   gs {e:.2e}")
+                    worst = max(worst, e)
+    print("worst max-normalised error:", worst)
+    assert worst < 3e-4     # the oracle does not clamp the decay at e^-9: the w up to 2.5 cases differ by that much
+
+
+if __name__ == "__main__":
+    main()
