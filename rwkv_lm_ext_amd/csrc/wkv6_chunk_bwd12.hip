@@ -759,12 +759,16 @@ int want_split(int BH)
     return 2 * BH <= cu_count();
 }
 
-// Which chunked backward serves a call with BH (batch, head) pairs, hence how far apart the forward's checkpoints are:
-// the two-level 16-wave kernel (64) unless two workgroups have to share a pair (32).  WKV6_BWD=12 / 64 forces one (A/B switch).
+// Which chunked backward serves a call, hence how far apart the forward's checkpoints are.  Default: this 12-wave staged kernel
+// (checkpoints every 32 tokens).  WKV6_BWD=64 selects the two-level 16-wave kernel (wkv6_chunk_bwd64.hip, checkpoints every 64
+// tokens: half the checkpoint memory and traffic, forward 10 % faster, backward 21 % slower at config 2 -- profiles/r03_bwd64_*),
+// except where two workgroups share a (batch, head) pair (ScanArgs::split), which only this kernel can do.
 int chunk_ckpt_tok(int BH)
 {
-    if (const char* e = getenv("WKV6_BWD")) return atoi(e) == 12 ? STG : 64;
-    return want_split(BH) ? STG : 64;
+    if (const char* e = getenv("WKV6_BWD")) {
+        if (atoi(e) == 64) return want_split(BH) ? STG : 64;
+    }
+    return STG;
 }
 
 hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)

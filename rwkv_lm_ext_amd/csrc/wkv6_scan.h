@@ -23,9 +23,9 @@
 
 namespace wkv6 {
 
-// The chunked forward leaves an fp32 state checkpoint every chunk_ckpt_tok(B*H) tokens for the chunked backward: 64 for the
-// two-level backward (wkv6_chunk_bwd64.hip, one per chunk), 32 for the 12-wave staged backward (wkv6_chunk_bwd12.hip, one per
-// stage), which still serves the calls with so few (batch, head) pairs that two workgroups share one (ScanArgs::split).
+// The chunked forward leaves an fp32 state checkpoint every chunk_ckpt_tok(B*H) tokens for the chunked backward: 32 for the
+// 12-wave staged backward (wkv6_chunk_bwd12.hip, one per stage; the default), 64 for the two-level backward
+// (wkv6_chunk_bwd64.hip, one per chunk; WKV6_BWD=64).
 int chunk_ckpt_tok(int BH);                  // wkv6_chunk_bwd12.hip
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute is per device.

@@ -20,6 +20,7 @@ ap.add_argument("--no-time", action="store_true")
 ap.add_argument("--no-oracle", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
+os.environ["WKV6_SPLIT"] = "0"      # the two-level kernel for every shape (small batch*head counts would keep the 12-wave one)
 
 
 def run(which, r, k, v, w, u, gy, H, s0=None, use_ckpt=True):
