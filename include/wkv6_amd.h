@@ -116,7 +116,10 @@ int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, c
                      void* gk, void* gv, void* gw, void* gu, void* gs, void* workspace,
                      size_t workspace_bytes, unsigned flags, void* stream);
 /* lens: int32 [B] device array, number of leading tokens both scans cover (NULL: derive from mask).
- * workspace: wkv6bi_workspace_bytes() bytes (NULL: stream-ordered allocation for the duration of the call). */
+ * workspace: wkv6bi_workspace_bytes() bytes (NULL: stream-ordered allocation for the duration of the call), or only
+ * wkv6bi_kept_bytes() bytes -- the part that must live from a WKV6_BI_KEEP_CKPT forward to its backward (row lengths and the two
+ * scans' checkpoints); the fp32 [B,T,C] side buffers (one in the forward, four in the backward) are then stream-ordered scratch
+ * of the call. */
 int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
                       const void* k, const void* v, const void* w, const void* u, void* y,
                       void* workspace, size_t workspace_bytes, unsigned flags, void* stream);
@@ -125,6 +128,7 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
                        void* gr, void* gk, void* gv, void* gw, void* gu, void* workspace,
                        size_t workspace_bytes, unsigned flags, void* stream);
 size_t wkv6bi_workspace_bytes(int B, int T, int C, int H);
+size_t wkv6bi_kept_bytes(int B, int T, int C, int H);
 
 /* ---- partially reversed sequences: replaces the torch.gather round trips around the operator in the
  * bidirectional compositions -- src/model_bi.py:331-348 (k, v reversed, y un-reversed) and src/model_ext.py:410-437 (every

@@ -30,6 +30,7 @@ SIGNATURES = {
     "rwkv6_cuda_forward_fp32": (_I, [_I] * 4 + [_VP] * 8),
     "wkv6_backward_workspace_bytes": (_SZ, [_I] * 4),
     "wkv6bi_workspace_bytes": (_SZ, [_I] * 4),
+    "wkv6bi_kept_bytes": (_SZ, [_I] * 4),
     "wkv6_forward_ex": (_I, [_I] * 4 + [_VP] * 8 + [_U, _VP]),
     "wkv6_forward_ckpt_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ, _U, _VP]),
     "wkv6_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),

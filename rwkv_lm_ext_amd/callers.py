@@ -76,8 +76,14 @@ class Tmix_x060(nn.Module):
         return torch.cat([self.time_maa_w, self.time_maa_k, self.time_maa_v, self.time_maa_r, self.time_maa_g], 0).view(5, -1)
 
     def _use_fused(self, x):
+        """The fused HIP kernels serve bf16 GPU activations with bf16 GPU parameters and rows of at most 4096 channels in
+        multiples of 64 (csrc/wkv6_mix.hip: check_rows); anything else (fp32 parameters under autocast, a partly cast model,
+        wider rows) takes the eager path unless `fused` forces a choice."""
         if self.fused is None:
-            return x.is_cuda and x.dtype == torch.bfloat16
+            C = x.shape[-1]
+            ok = lambda t: t.is_cuda and t.dtype == torch.bfloat16
+            return (ok(x) and ok(self.time_maa_x) and ok(self.time_maa_w) and ok(self.ln_x.weight)
+                    and C % 64 == 0 and C <= 4096)
         return self.fused
 
     def jit_func(self, x, shifted=None, rev_n=None):

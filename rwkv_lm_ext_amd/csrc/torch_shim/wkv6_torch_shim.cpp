@@ -14,6 +14,8 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <limits>
+
 #include "wkv6_amd.h"
 
 namespace {
@@ -36,6 +38,12 @@ void need_btc(const Tensor& t, const char* name, int64_t B, int64_t T, int64_t C
     TORCH_CHECK(t.dim() == 3 && t.size(0) == B && t.size(1) == T && t.size(2) == C, name, " must be [B,T,C]");
 }
 void ok(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed with code ", rc, " (include/wkv6_amd.h)"); }
+// the C ABI takes B, T, C, H as int (the reference's own prototypes, cuda/wkv6_op.cpp:5-6): refuse sizes that would be narrowed
+void need_sizes(int64_t B, int64_t T, int64_t C, int64_t H)
+{
+    constexpr int64_t lim = std::numeric_limits<int>::max();
+    TORCH_CHECK(B >= 1 && T >= 1 && C >= 1 && H >= 1 && B <= lim && T <= lim && C <= lim && H <= lim, "B, T, C, H must be positive ints");
+}
 
 constexpr auto BF = at::kBFloat16;
 constexpr auto F32 = at::kFloat;
@@ -43,6 +51,7 @@ constexpr auto F32 = at::kFloat;
 // ---- wkv6 (cuda/wkv6_op.cpp:8-13): w is the fp32 tensor ew = -exp(w_raw)
 void wkv6_forward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tensor& k, Tensor& v, Tensor& w, Tensor& u, Tensor& y)
 {
+    need_sizes(B, T, C, H);
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", BF, r); need_btc(y, "y", B, T, C, BF, r);
     const DeviceGuard guard(r.device());
@@ -52,6 +61,7 @@ void wkv6_forward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tensor&
 void wkv6_backward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tensor& k, Tensor& v, Tensor& w, Tensor& u, Tensor& gy,
                    Tensor& gr, Tensor& gk, Tensor& gv, Tensor& gw, Tensor& gu)
 {
+    need_sizes(B, T, C, H);
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", BF, r); need_btc(gy, "gy", B, T, C, BF, r);
     need_btc(gr, "gr", B, T, C, BF, r); need_btc(gk, "gk", B, T, C, BF, r); need_btc(gv, "gv", B, T, C, BF, r);
@@ -66,6 +76,7 @@ void wkv6_backward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tensor
 void wkv6bi_forward(int64_t B, int64_t T, int64_t C, int64_t H, const Tensor& mask, Tensor& r, Tensor& k, Tensor& v, Tensor& w,
                     Tensor& u, Tensor& y)
 {
+    need_sizes(B, T, C, H);
     need(mask, "mask", at::kInt, r);
     TORCH_CHECK(mask.numel() == B * T, "mask must be [B,T]");
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
@@ -77,11 +88,14 @@ void wkv6bi_forward(int64_t B, int64_t T, int64_t C, int64_t H, const Tensor& ma
 void wkv6bi_backward(int64_t B, int64_t T, int64_t C, int64_t H, const Tensor& mask, Tensor& r, Tensor& k, Tensor& v, Tensor& w,
                      Tensor& u, Tensor& gy, Tensor& gr, Tensor& gk, Tensor& gv, Tensor& gw, Tensor& gu)
 {
+    need_sizes(B, T, C, H);
     need(mask, "mask", at::kInt, r);
+    TORCH_CHECK(mask.numel() == B * T, "mask must be [B,T]");
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", BF, r); need_btc(gy, "gy", B, T, C, BF, r);
     need_btc(gr, "gr", B, T, C, BF, r); need_btc(gk, "gk", B, T, C, BF, r); need_btc(gv, "gv", B, T, C, BF, r);
     need_btc(gw, "gw", B, T, C, BF, r); need(gu, "gu", BF, r);
+    TORCH_CHECK(gu.numel() == B * C, "gu must be [B,C]");
     const DeviceGuard guard(r.device());
     ok(wkv6bi_cuda_backward(B, T, C, H, mask.data_ptr<int>(), r.data_ptr(), k.data_ptr(), v.data_ptr(), w.data_ptr<float>(),
                             u.data_ptr(), gy.data_ptr(), gr.data_ptr(), gk.data_ptr(), gv.data_ptr(), gw.data_ptr(), gu.data_ptr(),
@@ -93,6 +107,7 @@ template <bool INFCTX>
 void state_forward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tensor& k, Tensor& v, Tensor& w, Tensor& u, Tensor& s,
                    Tensor& y)
 {
+    need_sizes(B, T, C, H);
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, BF, r); need(u, "u", BF, r); need(s, "s", BF, r); need_btc(y, "y", B, T, C, BF, r);
     TORCH_CHECK(s.numel() == (INFCTX ? B : 1) * H * 64 * 64, "s must be ", INFCTX ? "[B,H,N,N]" : "[H,N,N]");
@@ -108,6 +123,7 @@ template <bool INFCTX>
 void state_backward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tensor& k, Tensor& v, Tensor& w, Tensor& u, Tensor& s,
                     Tensor& gy, Tensor& gr, Tensor& gk, Tensor& gv, Tensor& gw, Tensor& gu, Tensor& gs)
 {
+    need_sizes(B, T, C, H);
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, BF, r); need(u, "u", BF, r); need(s, "s", BF, r); need_btc(gy, "gy", B, T, C, BF, r);
     need_btc(gr, "gr", B, T, C, BF, r); need_btc(gk, "gk", B, T, C, BF, r); need_btc(gv, "gv", B, T, C, BF, r);
@@ -124,6 +140,7 @@ void state_backward(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& r, Tenso
 void rwkv6_forward_bf16(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& state, Tensor& r, Tensor& k, Tensor& v, Tensor& w,
                         Tensor& u, Tensor& y)
 {
+    need_sizes(B, T, C, H);
     need(state, "state", F32, r);
     need_btc(r, "r", B, T, C, BF, r); need_btc(k, "k", B, T, C, BF, r); need_btc(v, "v", B, T, C, BF, r);
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", BF, r); need_btc(y, "y", B, T, C, BF, r);
@@ -135,6 +152,7 @@ void rwkv6_forward_bf16(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& stat
 void rwkv6_forward_fp32(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& state, Tensor& r, Tensor& k, Tensor& v, Tensor& w,
                         Tensor& u, Tensor& y)
 {
+    need_sizes(B, T, C, H);
     need(state, "state", F32, r);
     need_btc(r, "r", B, T, C, F32, r); need_btc(k, "k", B, T, C, F32, r); need_btc(v, "v", B, T, C, F32, r);
     need_btc(w, "w", B, T, C, F32, r); need(u, "u", F32, r); need_btc(y, "y", B, T, C, F32, r);
@@ -142,6 +160,19 @@ void rwkv6_forward_fp32(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& stat
     const DeviceGuard guard(r.device());
     ok(rwkv6_cuda_forward_fp32(B, T, C, H, state.data_ptr<float>(), r.data_ptr<float>(), k.data_ptr<float>(), v.data_ptr<float>(),
                                w.data_ptr<float>(), u.data_ptr<float>(), y.data_ptr<float>(), stream_of(r)), "rwkv6 forward_fp32");
+}
+
+// cuda/rwkv6_op.cpp:16-19: the reference's fp16 kernel widens every input to fp32, computes in fp32 and rounds y to fp16
+// (cuda/rwkv6.cu:8-71); fp16 -> fp32 is exact, so the fp32 kernel on widened copies, rounded once, gives the same values
+void rwkv6_forward_fp16(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& state, Tensor& r, Tensor& k, Tensor& v, Tensor& w,
+                        Tensor& u, Tensor& y)
+{
+    constexpr auto F16 = at::kHalf;
+    need_btc(r, "r", B, T, C, F16, r); need_btc(k, "k", B, T, C, F16, r); need_btc(v, "v", B, T, C, F16, r);
+    need(u, "u", F16, r); need_btc(y, "y", B, T, C, F16, r);
+    Tensor r32 = r.to(F32), k32 = k.to(F32), v32 = v.to(F32), u32 = u.to(F32).contiguous(), y32 = at::empty_like(r32);
+    rwkv6_forward_fp32(B, T, C, H, state, r32, k32, v32, w, u32, y32);
+    y.copy_(y32);
 }
 
 }  // namespace
@@ -163,6 +194,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     ic.def("backward", &state_backward<true>, "wkv6infctx backward");
     auto rw = m.def_submodule("rwkv6");
     rw.def("forward_bf16", &rwkv6_forward_bf16, "rwkv6 forward_bf16");
+    rw.def("forward_fp16", &rwkv6_forward_fp16, "rwkv6 forward_fp16");
     rw.def("forward_fp32", &rwkv6_forward_fp32, "rwkv6 forward_fp32");
 }
 
@@ -182,4 +214,4 @@ WKV6_SHIM_TORCH_LIBRARY(WKV6_SHIM_LIB(wkv6), m) { m.def("forward", wkv6_forward)
 WKV6_SHIM_TORCH_LIBRARY(WKV6_SHIM_LIB(wkv6bi), m) { m.def("forward", wkv6bi_forward); m.def("backward", wkv6bi_backward); }
 WKV6_SHIM_TORCH_LIBRARY(WKV6_SHIM_LIB(wkv6state), m) { m.def("forward", state_forward<false>); m.def("backward", state_backward<false>); }
 WKV6_SHIM_TORCH_LIBRARY(WKV6_SHIM_LIB(wkv6infctx), m) { m.def("forward", state_forward<true>); m.def("backward", state_backward<true>); }
-WKV6_SHIM_TORCH_LIBRARY(WKV6_SHIM_LIB(rwkv6), m) { m.def("forward_bf16", rwkv6_forward_bf16); m.def("forward_fp32", rwkv6_forward_fp32); }
+WKV6_SHIM_TORCH_LIBRARY(WKV6_SHIM_LIB(rwkv6), m) { m.def("forward_bf16", rwkv6_forward_bf16); m.def("forward_fp16", rwkv6_forward_fp16); m.def("forward_fp32", rwkv6_forward_fp32); }

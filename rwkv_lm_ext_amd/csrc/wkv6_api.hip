@@ -24,31 +24,43 @@ int check_shape(int B, int T, int C, int H)
 }
 
 // Scratch for callers that pass no workspace (the reference-signature entry points have no such argument): a stream-ordered
-// allocation (hipMallocAsync on the caller's stream, hipFreeAsync right behind the launches that use it), so concurrent streams
-// never share a buffer and nothing synchronises the device.  The device's default memory pool is told once to keep what it has
-// been given, which makes the steady state an O(1) pool hit.
+// allocation (hipMallocFromPoolAsync on the caller's stream, hipFreeAsync right behind the launches that use it), so concurrent
+// streams never share a buffer and nothing synchronises the device.  The memory comes from a pool this library owns (one per
+// device, created on first use), not from the device's default pool, whose settings belong to the host application; the pool
+// keeps up to SCRATCH_KEEP bytes between calls (the steady state of ordinary shapes is an O(1) pool hit) and gives the rest back.
+// Under stream capture the allocation becomes part of the graph like any other stream-ordered allocation; callers that
+// replay graphs should pass a workspace instead (every *_ex entry point takes one).
+constexpr unsigned long long SCRATCH_KEEP = 1ull << 30;
 struct StreamScratch {
     void* ptr = nullptr;
     hipStream_t st = nullptr;
-    void* get(size_t bytes, hipStream_t stream)
+    static hipMemPool_t pool_of(int dev)
     {
         static std::mutex mu;
-        static bool tuned[64] = {};
+        static hipMemPool_t pools[64] = {};
+        if (dev < 0 || dev >= 64) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pools[dev]) {
+            hipMemPoolProps props = {};
+            props.allocType = hipMemAllocationTypePinned;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
+            hipMemPool_t pool = nullptr;
+            if (hipMemPoolCreate(&pool, &props) != hipSuccess) return nullptr;
+            unsigned long long keep = SCRATCH_KEEP;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            pools[dev] = pool;
+        }
+        return pools[dev];
+    }
+    void* get(size_t bytes, hipStream_t stream)
+    {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-        if (dev >= 0 && dev < 64) {
-            std::lock_guard<std::mutex> lk(mu);
-            if (!tuned[dev]) {
-                hipMemPool_t pool;
-                if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-                    unsigned long long keep = ~0ull;
-                    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-                }
-                tuned[dev] = true;
-            }
-        }
         st = stream;
-        if (hipMallocAsync(&ptr, bytes, st) != hipSuccess) ptr = nullptr;
+        hipMemPool_t pool = pool_of(dev);
+        const hipError_t e = pool ? hipMallocFromPoolAsync(&ptr, bytes, pool, st) : hipMallocAsync(&ptr, bytes, st);
+        if (e != hipSuccess) ptr = nullptr;
         return ptr;
     }
     ~StreamScratch()
@@ -224,7 +236,13 @@ struct BiWorkspace {
     float* side[4];
 };
 static size_t bi_side_bytes(int B, int T, int C) { return align_up((size_t)B * T * C * sizeof(float)); }
-static BiWorkspace bi_carve(void* workspace, int B, int T, int C, int H)
+// the part that lives from the forward to the backward (lens, order, both scans' checkpoints); the four side buffers behind it
+// are per-call scratch
+size_t wkv6bi_kept_bytes(int B, int T, int C, int H)
+{
+    return align_up((size_t)2 * B * sizeof(int)) + 2 * wkv6_backward_workspace_bytes(B, T, C, H);
+}
+static BiWorkspace bi_carve(void* workspace, void* side, int B, int T, int C, int H)
 {
     char* p = reinterpret_cast<char*>(workspace);
     BiWorkspace w;
@@ -232,12 +250,35 @@ static BiWorkspace bi_carve(void* workspace, int B, int T, int C, int H)
     w.order = w.lens + B;
     p += align_up((size_t)2 * B * sizeof(int));
     for (int i = 0; i < 2; ++i) { w.scan[i] = reinterpret_cast<float*>(p); p += wkv6_backward_workspace_bytes(B, T, C, H); }
+    if (side) p = reinterpret_cast<char*>(side);
     for (int i = 0; i < 4; ++i) { w.side[i] = reinterpret_cast<float*>(p); p += bi_side_bytes(B, T, C); }
     return w;
 }
 size_t wkv6bi_workspace_bytes(int B, int T, int C, int H)
 {
-    return align_up((size_t)2 * B * sizeof(int)) + 2 * wkv6_backward_workspace_bytes(B, T, C, H) + 4 * bi_side_bytes(B, T, C);
+    return wkv6bi_kept_bytes(B, T, C, H) + 4 * bi_side_bytes(B, T, C);
+}
+// workspace == NULL: everything is stream-ordered scratch for the call; >= wkv6bi_workspace_bytes(): everything is carved from
+// it; >= wkv6bi_kept_bytes(): the caller keeps only the part that must survive until the backward and the `nside` fp32 side
+// buffers this call needs are stream-ordered scratch.  Returns false when the workspace is too small or the allocation fails.
+static bool bi_workspace(void* workspace, size_t workspace_bytes, int nside, int B, int T, int C, int H, hipStream_t st,
+                         StreamScratch& scratch, BiWorkspace& ws)
+{
+    const size_t full = wkv6bi_workspace_bytes(B, T, C, H), kept = wkv6bi_kept_bytes(B, T, C, H);
+    if (!workspace) {
+        workspace = scratch.get(full, st);
+        if (!workspace) return false;
+        ws = bi_carve(workspace, nullptr, B, T, C, H);
+    } else if (workspace_bytes >= full) {
+        ws = bi_carve(workspace, nullptr, B, T, C, H);
+    } else if (workspace_bytes >= kept) {
+        void* const side = scratch.get((size_t)nside * bi_side_bytes(B, T, C), st);
+        if (!side) return false;
+        ws = bi_carve(workspace, side, B, T, C, H);
+    } else {
+        return false;
+    }
+    return true;
 }
 
 int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
@@ -339,15 +380,9 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
     if (int rc = check_shape(B, T, C, H)) return rc;
     if (!r || !k || !v || !w || !u || !y || (!mask && !lens)) return WKV6_ENULL;
     hipStream_t st = (hipStream_t)stream;
-    const size_t need = wkv6bi_workspace_bytes(B, T, C, H);
     StreamScratch scratch;                     // released (stream-ordered) when this call returns
-    if (!workspace) {
-        workspace = scratch.get(need, (hipStream_t)stream);
-        if (!workspace) return WKV6_EWORKSPACE;
-    } else if (workspace_bytes < need) {
-        return WKV6_EWORKSPACE;
-    }
-    const BiWorkspace ws = bi_carve(workspace, B, T, C, H);
+    BiWorkspace ws;
+    if (!bi_workspace(workspace, workspace_bytes, 1, B, T, C, H, st, scratch, ws)) return WKV6_EWORKSPACE;
     if (!lens) {
         hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, ws.lens, T);
         lens = ws.lens;
@@ -378,15 +413,9 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
     if (int rc = check_shape(B, T, C, H)) return rc;
     if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw || (!mask && !lens)) return WKV6_ENULL;
     hipStream_t st = (hipStream_t)stream;
-    const size_t need = wkv6bi_workspace_bytes(B, T, C, H);
     StreamScratch scratch;                     // released (stream-ordered) when this call returns
-    if (!workspace) {
-        workspace = scratch.get(need, (hipStream_t)stream);
-        if (!workspace) return WKV6_EWORKSPACE;
-    } else if (workspace_bytes < need) {
-        return WKV6_EWORKSPACE;
-    }
-    const BiWorkspace ws = bi_carve(workspace, B, T, C, H);
+    BiWorkspace ws;
+    if (!bi_workspace(workspace, workspace_bytes, 4, B, T, C, H, st, scratch, ws)) return WKV6_EWORKSPACE;
     if (!lens) {
         hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, ws.lens, T);
         lens = ws.lens;

@@ -54,7 +54,21 @@ class _DDLerp(torch.autograd.Function):
             rc = _lib.load().wkv6_ddlerp_rev_backward(B, T, C, NS, _ptr(x), _ptr(shifted0), _ptr(m), _ptr(maa), _ptr(rev_n),
                                                       _ptr(dout), _ptr(dx), _ptr(dm), _ptr(part), nparts, _stream_ptr())
         _lib.check(rc, "ddlerp backward")
-        return dx, part.sum(0).to(maa.dtype), dm, None, None   # the token in front of the row (infctx carry) gets no gradient
+        dshift = None
+        if shifted0 is not None and ctx.needs_input_grad[3]:
+            # The token in front of the row (the infctx carry: the previous chunk's last token, src/model.py:1134-1190 passes the
+            # shift states through torch_checkpoint without detaching them) enters only the stream's first token t0:
+            # d shifted0[b] = sum_s dout[s,b,t0] (maa_s + m[s,b,t0]),  t0 = rev_n[b] - 1 where a reversed span starts the stream, else 0.
+            if rev_n is None:
+                d0 = dout[:, :, 0].float()
+                m0 = None if m is None else m[:, :, 0].float()
+            else:
+                t0 = (rev_n.clamp(0, T).long() - 1).clamp_min(0).view(1, B, 1, 1).expand(NS, B, 1, C)
+                d0 = dout.gather(2, t0)[:, :, 0].float()
+                m0 = None if m is None else m.gather(2, t0)[:, :, 0].float()
+            wgt = maa.float().view(NS, 1, C) + (0.0 if m0 is None else m0)
+            dshift = (d0 * wgt).sum(0).to(shifted0.dtype)
+        return dx, part.sum(0).to(maa.dtype), dm, dshift, None
 
 
 def ddlerp(x, maa, m=None, shifted0=None, rev_n=None):

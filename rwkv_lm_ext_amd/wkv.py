@@ -173,8 +173,9 @@ class WKV_6_BI(torch.autograd.Function):
             ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
             ctx.mask = mask
             ctx.save_for_backward(r, k, v, w, u)
-            # when a backward will follow, both scans leave their state checkpoints in the workspace
-            ctx.ws = wkv6_op.bi_new_workspace(B, T, C, H, r.device) if _keep_ckpt(ctx) else None
+            # when a backward will follow, both scans leave their state checkpoints in a buffer kept on ctx: 16 B per
+            # token-channel (8 per scan); the fp32 side buffers of the two calls are scratch of each call, not retained
+            ctx.ws = wkv6_op.bi_new_kept(B, T, C, H, r.device) if _keep_ckpt(ctx) else None
             return wkv6_op.bi_forward_ex(mask, r, k, v, w, u, H, ws=ctx.ws)
 
     @staticmethod

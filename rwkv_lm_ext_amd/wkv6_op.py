@@ -335,6 +335,13 @@ def bi_new_workspace(B, T, C, H, device):
     return torch.empty(_lib.load().wkv6bi_workspace_bytes(B, T, C, H), dtype=torch.uint8, device=device)
 
 
+def bi_new_kept(B, T, C, H, device):
+    """The part of the wkv6_bi workspace that has to live from the forward to the backward (row lengths, order, the state
+    checkpoints of both scans: 16 B per token-channel at 32-token checkpoint spacing); passed as `ws`, the fp32 side buffers
+    (4 B per token-channel in the forward, 16 B in the backward) become per-call scratch of the library."""
+    return torch.empty(_lib.load().wkv6bi_kept_bytes(B, T, C, H), dtype=torch.uint8, device=device)
+
+
 def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None, ws=None):
     """ws: a bi_new_workspace() buffer the caller keeps for bi_backward_ex(..., ws=ws): the forward then stores the state
     checkpoints of both scans in it and the backward skips its two state passes."""

@@ -48,13 +48,14 @@ def test_ddlerp_forward_backward(mix, ns, has_m, carry):
     x = rnd(B, T, C, seed=1).requires_grad_(True)
     maa = rnd(ns, C, scale=0.5, seed=2).requires_grad_(True)
     m = rnd(ns, B, T, C, scale=0.3, seed=3).requires_grad_(True) if has_m else None
-    first = rnd(B, C, seed=4) if carry else None
+    first = rnd(B, C, seed=4).requires_grad_(True) if carry else None
     out = mix.ddlerp(x, maa, m, first)
     assert out.shape == (ns, B, T, C) and out.dtype == bf
     # reference: the same math in fp32 on the CPU
     cpu = lambda t: None if t is None else t.detach().float().cpu().clone()
     xr, mr_, mm_ = cpu(x).requires_grad_(True), cpu(maa).requires_grad_(True), (cpu(m).requires_grad_(True) if has_m else None)
-    ref = ddlerp_ref(xr, mr_, mm_, cpu(first))
+    fr = cpu(first).requires_grad_(True) if carry else None
+    ref = ddlerp_ref(xr, mr_, mm_, fr)
     close(out, ref, "ddlerp out")
     dout = rnd(ns, B, T, C, seed=5)
     out.backward(dout)
@@ -63,6 +64,49 @@ def test_ddlerp_forward_backward(mix, ns, has_m, carry):
     if has_m:
         close(m.grad, mm_.grad, "ddlerp dm")
     assert max_norm_err(maa.grad.float().cpu().numpy(), mr_.grad.numpy()) <= 1e-2
+    if carry:       # the token in front of the row (infctx carry) receives the gradient of the first token's blends
+        close(first.grad, fr.grad, "ddlerp dshifted0", ulps=1.5)
+
+
+def test_ddlerp_carry_gradient_on_a_reversed_stream(mix):
+    """With a reversed leading span the stream starts at token rev_n - 1: that token's blends carry the gradient of the
+    token in front of the row.  Against the gather formulation (reverse x and m, plain shift)."""
+    ns, B, T, C = 5, 4, 29, 128
+    rev_n = torch.tensor([0, 1, 13, T], dtype=torch.int32, device="cuda")
+    x, maa, m = rnd(B, T, C, seed=1), rnd(ns, C, scale=0.5, seed=2), rnd(ns, B, T, C, scale=0.3, seed=3)
+    first = rnd(B, C, seed=4).requires_grad_(True)
+    dout = rnd(ns, B, T, C, seed=5)
+    mix.ddlerp(x, maa, m, first, rev_n).backward(dout)
+    ar = torch.arange(T, device="cuda").view(1, T).expand(B, T)
+    n = rev_n.long().view(B, 1)
+    idx = torch.where(ar < n, n - 1 - ar, ar)                                  # stream position -> token
+    gat = lambda t: torch.gather(t, t.dim() - 2, idx.view(*([1] * (t.dim() - 3)), B, T, 1).expand(*t.shape[:-1], C))
+    first2 = first.detach().clone().requires_grad_(True)
+    mix.ddlerp(gat(x).contiguous(), maa, gat(m).contiguous(), first2, None).backward(gat(dout).contiguous())
+    assert torch.equal(first.grad, first2.grad)
+
+
+def test_infctx_shift_state_gradient_fused_vs_unfused():
+    """time_mix through the infctx carry (src/model.py:773-782 keeps the shift state in the graph): the gradient of the incoming
+    shift state from the fused HIP path against the eager path."""
+    from oracle import caller_weights as cw
+    from rwkv_lm_ext_amd import callers, infctx
+    tm = callers.Tmix_x060(cw.N_EMBD, cw.DIM_ATT)
+    tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
+    tm = tm.cuda().to(bf)
+    B, T, C = 2, 24, cw.N_EMBD
+    x = rnd(B, T, C, seed=21)
+    grads = {}
+    for fused in (True, False):
+        tm.fused = fused
+        shift = rnd(B, C, seed=22).requires_grad_(True)
+        wkv = rnd(B, tm.n_head, 64, 64, scale=0.3, seed=23)
+        out, _ = infctx.tmix_forward_infctx(tm, x, infctx.TimeMixState(shift, wkv))
+        out.backward(rnd(B, T, C, seed=24))
+        grads[fused] = shift.grad.float()
+    tm.fused = None
+    err = (grads[True] - grads[False]).abs().max() / grads[False].abs().max()
+    assert float(err) <= 2e-2, float(err)        # two bf16 pipelines (one rounding per blend vs several in the eager chain)
 
 
 def test_group_norm_gate_forward_backward(mix):

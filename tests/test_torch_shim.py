@@ -21,12 +21,12 @@ def shim():
 def test_shim_builds_and_registers_every_operator(shim):
     for sub, fns in (("wkv6", ("forward", "backward")), ("wkv6_bi", ("forward", "backward")),
                      ("wkv6state", ("forward", "backward")), ("wkv6infctx", ("forward", "backward")),
-                     ("rwkv6", ("forward_bf16", "forward_fp32"))):
+                     ("rwkv6", ("forward_bf16", "forward_fp16", "forward_fp32"))):
         for fn in fns:
             assert callable(getattr(getattr(shim, sub), fn))
     for ns, fns in (("shim_wkv6", ("forward", "backward")), ("shim_wkv6bi", ("forward", "backward")),
                     ("shim_wkv6state", ("forward", "backward")), ("shim_wkv6infctx", ("forward", "backward")),
-                    ("shim_rwkv6", ("forward_bf16", "forward_fp32"))):
+                    ("shim_rwkv6", ("forward_bf16", "forward_fp16", "forward_fp32"))):
         for fn in fns:
             assert getattr(getattr(torch.ops, ns), fn) is not None
     # stricter than the reference shim: CPU tensors are rejected before anything is launched
