@@ -19,6 +19,18 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
+def load_golden_mid(name):
+    """The T = 160 fixtures of oracle/gen_golden_medium.py: inputs stored as raw bf16 bits (`<name>_bf16`, uint16) are returned
+    as the float32 values they stand for."""
+    out = {}
+    for k, v in load_golden(name).items():
+        if k.endswith("_bf16"):
+            out[k[:-5]] = (v.astype(np.uint32) << 16).view(np.float32)
+        else:
+            out[k] = v
+    return out
+
+
 def max_norm_err(a, b, floor=1e-3):
     """max|a-b| / max(max|b|, floor)  -- the metric every fp32 tolerance in this suite is stated in.
     `floor` keeps an all-zero expectation (gw at T <= 2) from turning fp32 cancellation noise into inf;

@@ -2,7 +2,16 @@
 the reference's modules, plus one bi-encoder training step (config 3 shape family: query/positive/negative, InfoNCE)
 whose gradients are checked against fp32 autograd through the pure-PyTorch port on the CPU.
 
-Tolerance: whole bf16 modules (bf16 GEMMs, bf16 activations) against the fp32 reference: max|d|/max|ref| <= 3e-2."""
+Three yardsticks (measured values in brackets, MI355X, round 3):
+(1) against the reference's fp32 vectors a whole bf16 module (bf16 GEMMs, bf16 activations) can only be held to
+    max|d|/max|ref| <= 3e-2 -- that gap is the modules' precision, not the kernels';
+(2) against the SAME bf16 module on the CPU (`bf16_cpu_twin`: eager torch, the WKV operator replaced by the pure-PyTorch port of
+    the reference's CPU recurrence) the gap is as wide [time-mix 2.1e-2, encoder hidden 1.2e-2, gradients 4.0e-2]: two bf16
+    pipelines that round at different points (the eager chain rounds every intermediate, the fused kernels once per blend);
+(3) against the same GPU module with ONLY the operator swapped for that port (`swap_wkv`: same GEMM backend, same fused
+    kernels, same rounding points) the operator is the only difference: OP_TOL [time-mix output 3.0e-3, encoder hidden 7.7e-3,
+    logits 4.4e-3]; parameter gradients of the training step 3e-2 [1.9e-2: the operator's bf16 gradients against fp32 autograd
+    through the port, accumulated over 12 x 32 tokens]."""
 import pytest
 import torch
 
@@ -12,7 +21,39 @@ from rwkv_lm_ext_amd import callers
 
 pytestmark = pytest.mark.gpu
 TOL = 3e-2
+TWIN_TOL = 3e-2          # yardstick (2)
+OP_TOL = 1e-2            # yardstick (3)
 bf = torch.bfloat16
+
+
+def _naive_bf16(B, T, C, H, r, k, v, w, u):
+    from oracle.wkv6_torch_naive import wkv6_naive
+    return wkv6_naive(r, k, v, w, u).to(bf)
+
+
+def swap_wkv(module):
+    """A copy of the GPU bf16 `module` whose time-mix blocks call the naive port of the reference's recurrence (torch ops on the
+    GPU, fp32 inside, y rounded to bf16) instead of the HIP operator; everything else identical."""
+    import copy
+    twin = copy.deepcopy(module)
+    for m in twin.modules():
+        if isinstance(m, callers.Tmix_x060):
+            m.wkv = _naive_bf16
+    return twin
+
+
+def bf16_cpu_twin(module):
+    """`module` (a CPU fp32 callers.* module) as a bf16 CPU module whose time-mix blocks call the naive port: the arithmetic
+    the GPU path is supposed to reproduce, at the GPU path's precision.  torch's CPU norms take bf16 inputs with fp32
+    parameters only."""
+    import copy
+    twin = copy.deepcopy(module).to(bf)
+    for m in twin.modules():
+        if isinstance(m, (torch.nn.GroupNorm, torch.nn.LayerNorm)):
+            m.float()
+        if isinstance(m, callers.Tmix_x060):
+            m.wkv, m.fused = _naive_bf16, False
+    return twin
 
 
 @pytest.fixture(scope="module")
@@ -28,6 +69,7 @@ def f32(t):
 def test_time_mix_and_bi_compositions_bf16(gold):
     tm = callers.Tmix_x060(cw.N_EMBD, cw.DIM_ATT)
     tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
+    twin = bf16_cpu_twin(tm)
     tm = tm.cuda().to(bf)
     x = gold["x"].cuda().to(bf)
     with torch.no_grad():
@@ -36,9 +78,17 @@ def test_time_mix_and_bi_compositions_bf16(gold):
         assert y.dtype == bf
         # the op on the module's own bf16 r,k,v,w against the reference WKV output
         assert max_norm_err(f32(y), gold["y"]) <= TOL
-        assert max_norm_err(f32(tm(x)), gold["out"]) <= TOL
+        out = tm(x)
+        assert max_norm_err(f32(out), gold["out"]) <= TOL
         out_bi = tm.forward_bi_c(x, gold["rev_idx"].cuda(), gold["mask"].cuda())
         assert max_norm_err(f32(out_bi), gold["out_bi"]) <= TOL
+        # the same module at the same precision on the CPU
+        xc = gold["x"].to(bf)
+        e1 = max_norm_err(f32(out), f32(twin(xc)))
+        e2 = max_norm_err(f32(out_bi), f32(twin.forward_bi_c(xc, gold["rev_idx"], gold["mask"])))
+        e3 = max_norm_err(f32(out), f32(swap_wkv(tm)(x)))
+        print(f"time-mix vs bf16 CPU twin: out {e1:.2e}, composition C {e2:.2e}; operator swapped on the GPU: {e3:.2e}")
+        assert e1 <= TWIN_TOL and e2 <= TWIN_TOL and e3 <= OP_TOL, (e1, e2, e3)
 
 
 def test_composition_b_on_gpu_vs_oracle(gold, oracle):
@@ -82,6 +132,7 @@ def test_composition_b_on_gpu_vs_oracle(gold, oracle):
 def test_encoder_bf16(gold):
     enc = callers.RwkvEncoder(cw.VOCAB, cw.N_EMBD, cw.N_LAYER, cw.DIM_ATT, cw.DIM_FFN)
     enc.load_state_dict(cw.encoder_weights(), strict=True)
+    twin = bf16_cpu_twin(enc)
     enc = enc.cuda().to(bf)
     idx = gold["idx"].cuda()
     with torch.no_grad():
@@ -89,6 +140,12 @@ def test_encoder_bf16(gold):
         assert max_norm_err(f32(hidden), gold["hidden"]) <= TOL
         assert max_norm_err(f32(logits), gold["logits"]) <= TOL
         assert max_norm_err(f32(enc.encode_sentence(idx)), gold["sent"]) <= TOL
+        lt, ht = twin(gold["idx"], True)
+        e1, e2 = max_norm_err(f32(hidden), f32(ht)), max_norm_err(f32(logits), f32(lt))
+        lo, ho = swap_wkv(enc)(idx, True)
+        e3, e4 = max_norm_err(f32(hidden), f32(ho)), max_norm_err(f32(logits), f32(lo))
+        print(f"encoder vs bf16 CPU twin: hidden {e1:.2e}, logits {e2:.2e}; operator swapped on the GPU: {e3:.2e}, {e4:.2e}")
+        assert e1 <= TWIN_TOL and e2 <= TWIN_TOL and e3 <= OP_TOL and e4 <= OP_TOL, (e1, e2, e3, e4)
 
 
 def test_bi_encoder_training_step_gradients():
@@ -117,18 +174,32 @@ def test_bi_encoder_training_step_gradients():
     ref = make(wkv=lambda B, T_, C, H, r, k, v, w, u: wkv6_naive(r, k, v, w, u))        # fp32, CPU, autograd
     loss_ref = step(ref, idx)
     loss_ref.backward()
+    twin = bf16_cpu_twin(make())                                                        # bf16, CPU, autograd
+    loss_twin = step(twin, idx)
+    loss_twin.backward()
     enc = make().cuda().to(bf)
+    swapped = swap_wkv(enc)                                                             # GPU, bf16, only the operator differs
     loss = step(enc, idx.cuda())
     loss.backward()
-    assert abs(float(loss) - float(loss_ref)) <= 5e-2 * max(1.0, abs(float(loss_ref)))
-    checked = 0
-    for (n, p), (_, pr) in zip(enc.named_parameters(), ref.named_parameters()):
+    loss_sw = step(swapped, idx.cuda())
+    loss_sw.backward()
+    assert abs(float(loss) - float(loss_ref)) <= 1e-2, (float(loss), float(loss_ref))     # [1.4e-3] a bf16 model against its fp32 self
+    assert abs(float(loss) - float(loss_twin)) <= 2e-2, (float(loss), float(loss_twin))   # [9e-3]
+    assert abs(float(loss) - float(loss_sw)) <= 5e-3, (float(loss), float(loss_sw))
+    checked, worst, worst_ref, worst_sw = 0, 0.0, 0.0, 0.0
+    for (n, p), (_, pr), (_, pt), (_, ps) in zip(enc.named_parameters(), ref.named_parameters(), twin.named_parameters(),
+                                                 swapped.named_parameters()):
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
         if any(s in n for s in ("time_faaaa", "time_decay", "key.weight", "value.weight", "receptance.weight")) and "ffn" not in n:
             # parameters whose gradient flows through the WKV backward kernels
-            e = max_norm_err(f32(p.grad), pr.grad)
-            assert e <= 0.12, (n, e)
+            e_ref, e, e_sw = max_norm_err(f32(p.grad), pr.grad), max_norm_err(f32(p.grad), f32(pt.grad)), max_norm_err(f32(p.grad), f32(ps.grad))
+            worst, worst_ref, worst_sw = max(worst, e), max(worst_ref, e_ref), max(worst_sw, e_sw)
+            assert e_ref <= 6e-2, (n, e_ref)                # [3.6e-2] against fp32: the bf16 model's own precision
+            assert e <= 6e-2, (n, e)                        # [4.0e-2] against the same bf16 model on the CPU: two bf16 pipelines
+            assert e_sw <= 3e-2, (n, e_sw)                  # [1.9e-2] the operator's backward against autograd through the naive port
             checked += 1
+    print(f"training step: worst gradient difference vs bf16 CPU twin {worst:.2e}, vs fp32 {worst_ref:.2e}, operator swapped on the "
+          f"GPU {worst_sw:.2e}; loss {float(loss):.4f} / twin {float(loss_twin):.4f} / fp32 {float(loss_ref):.4f} / swapped {float(loss_sw):.4f}")
     assert checked >= 8
 
 

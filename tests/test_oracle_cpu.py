@@ -172,3 +172,29 @@ def test_python_constants_match_the_header():
     for name, value in pairs.items():
         assert enums[name] == value, name
     assert _lib.REV_ALL == _lib.REV_R | _lib.REV_K | _lib.REV_V | _lib.REV_W | _lib.REV_Y
+
+
+def test_oracle_matches_the_medium_reference_fixtures(oracle):
+    """T = 160 vectors generated from the reference's CPU recurrence (oracle/gen_golden_medium.py): plain, per-sample state
+    (gs, final state), ragged wkv6_bi."""
+    from conftest import load_golden_mid
+    g = load_golden_mid("wkv6_mid")
+    a = [g[n] for n in ("r", "k", "v", "w", "u")]
+    assert max_norm_err(oracle.forward(*a), g["y"]) <= 2e-5
+    og = oracle.backward(*a, g["gy"])
+    for n in ("gr", "gk", "gv", "gw", "gu"):
+        assert max_norm_err(og[n], g[n]) <= 2e-5, n
+    g = load_golden_mid("wkv6_mid_state")
+    a = [g[n] for n in ("r", "k", "v", "w", "u")]
+    y, so = oracle.forward(*a, g["s"], return_state=True)
+    assert max_norm_err(y, g["y"]) <= 2e-5 and max_norm_err(so, g["s_final"]) <= 2e-5
+    og = oracle.backward(*a, g["gy"], g["s"])
+    for n, m in (("gr", "gr"), ("gk", "gk"), ("gv", "gv"), ("gw", "gw"), ("gu", "gu"), ("gs_b", "gs")):
+        assert max_norm_err(og[n], g[m]) <= 2e-5, n
+    g = load_golden_mid("wkv6_mid_bi")
+    a = [g[n] for n in ("r", "k", "v", "w", "u")]
+    mask = g["mask"].astype(np.int32)
+    assert max_norm_err(oracle.bi_forward(mask, *a), g["y"]) <= 2e-5
+    ob = oracle.bi_backward(mask, *a, g["gy"])
+    for n in ("gr", "gk", "gv", "gw", "gu"):
+        assert max_norm_err(ob[n], g[n]) <= 2e-5, n

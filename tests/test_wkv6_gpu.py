@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import bf16_report, load_golden, max_norm_err
+from conftest import bf16_report, load_golden, load_golden_mid, max_norm_err
 
 pytestmark = pytest.mark.gpu
 
@@ -174,6 +174,50 @@ def test_golden_bi(ops, io):
         check(t, g[n], io, "bi " + n)
         assert np.all(host(t)[1, 18:] == 0)
     assert max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"]) <= (F32_TOL if io == torch.float32 else PART_TOL)
+
+
+@pytest.mark.parametrize("bwd", ["12", "64"], ids=["bwd12", "bwd64"])
+@pytest.mark.parametrize("io", IOS, ids=["f32", "bf16"])
+def test_golden_medium(ops, monkeypatch, io, bwd):
+    """Reference-generated vectors at T = 160 (oracle/gen_golden_medium.py): every block, stage, group and checkpoint boundary of
+    the chunked kernels meets values that came out of the reference's own recurrence -- plain, per-sample state with gs and
+    final state, ragged wkv6_bi; fp32 I/O (scan kernels) and bf16 I/O through either chunked backward."""
+    if bwd == "64":
+        if io == torch.float32:
+            pytest.skip("the backward switch only concerns the chunked bf16 kernels")
+        monkeypatch.setenv("WKV6_BWD", "64")
+        monkeypatch.setenv("WKV6_SPLIT", "0")
+    tol = F32_TOL if io == torch.float32 else PART_TOL
+    g = load_golden_mid("wkv6_mid")
+    H = g["u"].shape[0]
+    B, T, C = g["r"].shape
+    r, k, v, w, u, gy = (dev(g[n], io) for n in ("r", "k", "v", "w", "u", "gy"))
+    ck = ops.new_checkpoint(B, T, C, H, "cuda") if io == torch.bfloat16 else None
+    check(ops.forward_ex(r, k, v, w, u, H, ckpt=ck), g["y"], io, "mid y")
+    gr, gk, gv, gw, gu, _ = ops.backward_ex(r, k, v, w, u, gy, H, ckpt=ck)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+        check(t, g[n], io, "mid " + n)
+    assert max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"]) <= tol
+    g = load_golden_mid("wkv6_mid_state")
+    H = g["u"].shape[0]
+    r, k, v, w, u, gy, s = (dev(g[n], io) for n in ("r", "k", "v", "w", "u", "gy", "s"))
+    s_out = torch.empty_like(s)
+    check(ops.forward_ex(r, k, v, w, u, H, s0=s, s_out=s_out), g["y"], io, "mid state y")
+    check(s_out, g["s_final"], io, "mid final state")
+    gr, gk, gv, gw, gu, gs = ops.backward_ex(r, k, v, w, u, gy, H, s0=s, want_gs=True)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw), ("gs", gs.to(io))):
+        check(t, g[n], io, "mid state " + n)
+    assert max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"]) <= tol
+    g = load_golden_mid("wkv6_mid_bi")
+    H = g["u"].shape[0]
+    r, k, v, w, u, gy = (dev(g[n], io) for n in ("r", "k", "v", "w", "u", "gy"))
+    mask = torch.from_numpy(g["mask"].astype(np.int32)).cuda()
+    check(ops.bi_forward_ex(mask, r, k, v, w, u, H), g["y"], io, "mid bi y")
+    gr, gk, gv, gw, gu = ops.bi_backward_ex(mask, r, k, v, w, u, gy, H)
+    for n, t in (("gr", gr), ("gk", gk), ("gv", gv), ("gw", gw)):
+        check(t, g[n], io, "mid bi " + n)
+        assert np.all(host(t)[2, 33:] == 0) and np.all(host(t)[1, 97:] == 0)
+    assert max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"]) <= tol
 
 
 @pytest.mark.parametrize("io", IOS, ids=["f32", "bf16"])
