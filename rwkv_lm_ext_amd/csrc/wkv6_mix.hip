@@ -91,16 +91,70 @@ __global__ void ddlerp_bwd_kernel(const LerpArgs a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[s][q] = 0.f;
     }
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    if (!a.rev_n) {
+        // Plain stream: a workgroup walks a contiguous run of rows backwards, so what token t+1 hands to token t -- the part of
+        // its blends that came from x_t:  sum_s dout[s][t+1] (maa_s + m_s[t+1])  -- is four floats carried in registers
+        // instead of a second read of dout and m (54 -> 34 bytes per token-channel at NS = 5).
+        const long per = (rows + gridDim.x - 1) / gridDim.x, r0 = (long)blockIdx.x * per, r1 = min(rows, r0 + per);
+        float carry[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r1 > r0 && r1 < rows && r1 % a.T != 0) {          // the run ends inside a sequence: fetch the next row's hand-over once
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float dn[4], mn[4] = {0.f, 0.f, 0.f, 0.f};
+                ld4(a.dout + s * plane + r1 * a.C + c, dn);
+                if constexpr (HAS_M) ld4(a.m + s * plane + r1 * a.C + c, mn);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) carry[q] = fmaf(dn[q], maa[s][q] + mn[q], carry[q]);
+            }
+        }
+        for (long row = r1 - 1; row >= r0; --row) {
+            const int t = (int)(row % a.T), b = (int)(row / a.T);
+            float x[4], xp[4] = {0.f, 0.f, 0.f, 0.f}, g[4], own[4] = {0.f, 0.f, 0.f, 0.f};
+            ld4(a.x + row * a.C + c, x);
+            if (t > 0) ld4(a.x + (row - 1) * a.C + c, xp);
+            else if (a.shifted0) ld4(a.shifted0 + (long)b * a.C + c, xp);
+            const bool last = t == a.T - 1;                       // nothing behind the last token of a sequence
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = last ? 0.f : carry[q];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float d[4], m[4] = {0.f, 0.f, 0.f, 0.f}, dm[4];
+                ld4(a.dout + s * plane + row * a.C + c, d);
+                if constexpr (HAS_M) ld4(a.m + s * plane + row * a.C + c, m);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float wgt = maa[s][q] + m[q];
+                    g[q] = fmaf(d[q], 1.f - wgt, g[q]);
+                    own[q] = fmaf(d[q], wgt, own[q]);
+                    dm[q] = d[q] * (xp[q] - x[q]);
+                    acc[s][q] += dm[q];
+                }
+                if constexpr (HAS_M) io4<bf16_t>::store(a.dm + s * plane + row * a.C + c, dm);
+            }
+            io4<bf16_t>::store(a.dx + row * a.C + c, g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) carry[q] = own[q];
+        }
+    } else
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {       // reversed-span streams: the neighbours are not adjacent rows
         const int t = (int)(row % a.T), b = (int)(row / a.T);
         float x[4], xp[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
         ld4(a.x + row * a.C + c, x);
-        const int nrev = a.rev_n ? min(max(a.rev_n[b], 0), a.T) : 0;
+        const int nrev = min(max(a.rev_n[b], 0), a.T);
         const int tp = prev_tok(t, nrev), tn = next_tok(t, nrev, a.T);
         if (tp >= 0) ld4(a.x + ((long)b * a.T + tp) * a.C + c, xp);
         else if (a.shifted0) ld4(a.shifted0 + (long)b * a.C + c, xp);
-        const bool has_next = tn >= 0;
-        const long rown = (long)b * a.T + tn;
+        if (tn >= 0) {                                        // (summed in the order of the plain path: the two agree bit for bit)
+            const long rown = (long)b * a.T + tn;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float dn[4], mn[4] = {0.f, 0.f, 0.f, 0.f};
+                ld4(a.dout + s * plane + rown * a.C + c, dn);
+                if constexpr (HAS_M) ld4(a.m + s * plane + rown * a.C + c, mn);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = fmaf(dn[q], maa[s][q] + mn[q], g[q]);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             float d[4], m[4] = {0.f, 0.f, 0.f, 0.f};
@@ -109,19 +163,11 @@ __global__ void ddlerp_bwd_kernel(const LerpArgs a)
             float dm[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float xx = xp[q] - x[q];
                 g[q] = fmaf(d[q], 1.f - (maa[s][q] + m[q]), g[q]);
-                dm[q] = d[q] * xx;
+                dm[q] = d[q] * (xp[q] - x[q]);
                 acc[s][q] += dm[q];
             }
             if constexpr (HAS_M) io4<bf16_t>::store(a.dm + s * plane + row * a.C + c, dm);
-            if (has_next) {
-                float dn[4], mn[4] = {0.f, 0.f, 0.f, 0.f};
-                ld4(a.dout + s * plane + rown * a.C + c, dn);
-                if constexpr (HAS_M) ld4(a.m + s * plane + rown * a.C + c, mn);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] = fmaf(dn[q], maa[s][q] + mn[q], g[q]);
-            }
         }
         io4<bf16_t>::store(a.dx + row * a.C + c, g);
     }
