@@ -109,6 +109,16 @@ int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, co
 int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                          const void* w, const void* u, const void* s0, void* s_out, void* y,
                          void* ckpt, size_t ckpt_bytes, unsigned flags, void* stream);
+/* wkv6_forward_ckpt_ex with the per-head GroupNorm and the gate multiply that follow the operator in the time-mix block
+ * (src/model.py:462-468: x = ln_x(x.view(B*T, C)).view(B, T, C); output(x * g)) fused into its store:
+ *     out = GroupNorm_H(y; gamma, beta, eps) * gate,       y = the operator's bf16 output, exactly what nn.GroupNorm would see.
+ * y may be NULL (inference: only `out` is written); ckpt may be NULL; stats (fp32 [B*T, H, 2]: mean, rstd per token and head,
+ * what wkv6_gn_gate_backward consumes) may be NULL.  gate [B,T,C], gamma / beta [C], bf16.  bf16 I/O, chunked kernels only.
+ * Returns WKV6_EUNSUPPORTED where the fusion does not apply (WKV6_IO_F32 / WKV6_ALGO_SCAN; so few (batch, head) pairs that two
+ * workgroups share one): the caller then runs wkv6_forward_ckpt_ex + wkv6_gn_gate_forward. */
+int wkv6_forward_gn_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v, const void* w, const void* u,
+                       const void* s0, void* s_out, void* y, void* ckpt, size_t ckpt_bytes, const void* gate, const void* gamma,
+                       const void* beta, float eps, void* out, float* stats, unsigned flags, void* stream);
 /* gu, gs may be NULL (skipped).  workspace: wkv6_backward_workspace_bytes() bytes, or NULL: the library takes a stream-ordered
  * allocation on `stream` for the duration of the call (hipMallocAsync / hipFreeAsync; safe from any number of streams). */
 int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,

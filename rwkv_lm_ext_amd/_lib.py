@@ -33,6 +33,7 @@ SIGNATURES = {
     "wkv6bi_kept_bytes": (_SZ, [_I] * 4),
     "wkv6_forward_ex": (_I, [_I] * 4 + [_VP] * 8 + [_U, _VP]),
     "wkv6_forward_ckpt_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ, _U, _VP]),
+    "wkv6_forward_gn_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ] + [_VP] * 3 + [_F] + [_VP] * 2 + [_U, _VP]),
     "wkv6_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
     "wkv6_forward_rev_ex": (_I, [_I] * 4 + [_VP] * 7 + [_SZ, _VP, _U, _U, _VP]),
     "wkv6_backward_rev_ex": (_I, [_I] * 4 + [_VP] * 12 + [_SZ, _VP, _U, _U, _VP]),
@@ -52,6 +53,7 @@ SIGNATURES = {
 W_EW_F32, W_RAW, IO_F32, S0_PER_BATCH, ALGO_SCAN, CKPT_VALID, BI_KEEP_CKPT, PARTIALS_F32 = 0, 1, 2, 4, 16, 32, 64, 128
 REV_R, REV_K, REV_V, REV_W, REV_Y, REV_ALL = 1, 2, 4, 8, 16, 31      # wkv6_*_rev_ex: tensors held in reversed order
 
+EUNSUPPORTED = -4
 ERRORS = {-1: "WKV6_EINVAL (shape: need C == H*64 and B,T,C,H >= 1)", -2: "WKV6_ENULL (null pointer)",
           -3: "WKV6_EWORKSPACE (workspace too small / allocation failed)", -4: "WKV6_EUNSUPPORTED"}
 

@@ -52,6 +52,11 @@ class Tmix_x060(nn.Module):
         self.n_head = dim_att // head_size
         self.wkv = wkv or _default_wkv
         self.fused = fused
+        # forward(): GroupNorm * gate inside the operator's forward kernel (wkv.WKV_6_GN) instead of a second kernel.  Off by
+        # default: it saves the y round trip through HBM but the layer is not faster for it -- B x T = 48 x 512, C = 2048 on
+        # MI355X: fwd+bwd 6.644 vs 6.626 ms, forward only 1.612 vs 1.593 ms (profiles/r03_tmix_layer_epilogue.txt): the 56 us
+        # GroupNorm kernel runs at 5.4 TB/s, and the statistics exchange lengthens the forward's consumer waves by as much.
+        self.fuse_epilogue = False
         d_mix = 64 if n_embd == 4096 else 32                              # TIME_MIX_EXTRA_DIM
         d_decay = 128 if n_embd == 4096 else 64                           # TIME_DECAY_EXTRA_DIM
         z = lambda *s: nn.Parameter(torch.zeros(*s))
@@ -131,8 +136,16 @@ class Tmix_x060(nn.Module):
         return self.wkv(B, T, C, self.n_head, r, k, v, w, self.time_faaaa)
 
     def forward(self, x):
-        """causal time-mix (src/model.py:470-477)."""
+        """causal time-mix (src/model.py:470-477).  With the HIP operator on bf16 GPU tensors the operator, the per-head
+        GroupNorm and the gate multiply are ONE kernel (wkv.WKV_6_GN): y never leaves the chip on its way to
+        the normalisation."""
         r, k, v, g, w = self.jit_func(x)
+        if self.wkv is _default_wkv and self._use_fused(x) and self.fuse_epilogue:
+            from .wkv import RUN_CUDA_RWKV6_GN
+            B, T, C = r.shape
+            gated = RUN_CUDA_RWKV6_GN(B, T, C, self.n_head, *(t.contiguous() for t in (r, k, v, w)), self.time_faaaa, g,
+                                      self.ln_x.weight, self.ln_x.bias, self.ln_x.eps)
+            return self.output(gated)
         return self.jit_func_2(self._run(r, k, v, w), g)
 
     def _rev_wkv(self, r, k, v, w, rev_n, rev_mask):

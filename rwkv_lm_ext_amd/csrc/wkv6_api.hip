@@ -312,6 +312,25 @@ int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* 
     return to_rc(chunk_forward(a, (hipStream_t)stream));
 }
 
+int wkv6_forward_gn_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v, const void* w, const void* u,
+                       const void* s0, void* s_out, void* y, void* ckpt, size_t ckpt_bytes, const void* gate, const void* gamma,
+                       const void* beta, float eps, void* out, float* stats, unsigned flags, void* stream)
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!r || !k || !v || !w || !u || !gate || !gamma || !beta || !out) return WKV6_ENULL;
+    if (flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) return WKV6_EUNSUPPORTED;
+    if (ckpt && ckpt_bytes < wkv6_backward_workspace_bytes(B, T, C, H)) return WKV6_EWORKSPACE;
+    if (want_split(B * H)) return WKV6_EUNSUPPORTED;      // two workgroups per (batch, head): a head's statistics span both
+    ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
+    a.s0 = s0;
+    a.s0_bstride = (flags & WKV6_S0_PER_BATCH) ? (long)H * HEAD * HEAD : 0;
+    a.s_out = s_out;
+    a.y = y;
+    a.ckpt = reinterpret_cast<float*>(ckpt);
+    a.gn_gate = gate; a.gn_gamma = gamma; a.gn_beta = beta; a.gn_eps = eps; a.gn_out = out; a.gn_stats = stats;
+    return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
+}
+
 int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                      const void* w, const void* u, const void* s0, const void* gy, void* gr,
                      void* gk, void* gv, void* gw, void* gu, void* gs, void* workspace,

@@ -44,10 +44,14 @@ constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 // With a.ckpt the state is dumped every a.ckpt_tok tokens (fp32, register order:
 // [wave][tile][lane][4]) for the backward kernel.
 // ACC: add into y (from a.y_f32 when given) instead of overwriting -- the reverse half of wkv6_bi.
-template <bool W_RAW, bool STATE_ONLY, bool ACC>
+// GN: the per-head GroupNorm and the gate multiply behind the operator (src/model.py:462-468) happen in the
+// store epilogue: a token's statistics span the head's 64 channels = the four consumer waves, which exchange their 16-channel
+// sums (of the bf16-rounded y, what nn.GroupNorm would see) through LDS at the group barrier the kernel has anyway and write
+// GroupNorm_H(y) * gate one group later from the y they kept in registers; y makes no round trip through HBM.
+template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false>
 __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES]
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2]
     const int tid = threadIdx.x, lane = tid & 63;
     // a.split (B*H <= half the CUs): two 6-wave workgroups per (batch, head) on two CUs, each with all four producers and two
     // of the four consumers (value columns [32 part, 32 part + 32)): hardware wave w plays consumer 2 part + w for w < 2 and
@@ -263,7 +267,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         }
         int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read, natural columns (this wave's V tile)
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
-        const rsrc_t rs_y = make_rsrc(gy_, (!STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
+        // (a null y -- the fused-epilogue forward of an inference call -- gets a zero-sized resource: its stores are dropped)
+        const rsrc_t rs_y = make_rsrc(a.y ? gy_ : nullptr, (!STATE_ONLY && a.y && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
         const unsigned ckt = (unsigned)a.ckpt_tok;                               // 32 (12-wave backward) or 64 (two-level backward)
         const unsigned nst = ((unsigned)a.T + ckt - 1) / ckt;                    // checkpoint slots of this (batch, head): 16 KB each
         // (two-level scan: this batch row is segment b % S of sequence b / S; the S segments' slots are consecutive, which is the
@@ -271,6 +276,44 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         const int segs = a.ckpt_segs > 1 ? a.ckpt_segs : 1;
         const long ck_slot0 = ((long)((b / segs) * a.H + h) * segs + b % segs) * nst;
         const rsrc_t rs_ck = make_rsrc(a.ckpt ? a.ckpt + ck_slot0 * (HEAD * HEAD) : nullptr, a.ckpt ? nst * 16384u : 0u);
+        // GN epilogue state: this group's y (bf16-rounded) and gate per block, the channel's affine parameters
+        float gn_y[NBLK][4], gn_ga[4] = {1.f, 1.f, 1.f, 1.f}, gn_be[4] = {0.f, 0.f, 0.f, 0.f};
+        uint2 gn_g[NBLK];
+        unsigned gn_off[NBLK];
+        char* const gn_stat = smem + 2 * GRP_BYTES;
+        const unsigned gn_bytes = (GN && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
+        const rsrc_t rs_gate = make_rsrc(GN ? reinterpret_cast<const bf16_t*>(a.gn_gate) + base : nullptr, gn_bytes);
+        const rsrc_t rs_out = make_rsrc(GN ? reinterpret_cast<bf16_t*>(a.gn_out) + base : nullptr, gn_bytes);
+        if constexpr (GN) {
+            io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.gn_gamma) + h * HEAD + 16 * wv + 4 * g, gn_ga);
+            io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.gn_beta) + h * HEAD + 16 * wv + 4 * g, gn_be);
+        }
+        // normalise, gate and store the blocks of group `grp` (after the barrier that published every wave's partial sums)
+        auto gn_finish = [&](int grp) {
+            const char* const st = gn_stat + (grp & 1) * 2048;
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const float2 t = *reinterpret_cast<const float2*>(st + ((ww * NBLK + blk) * 16 + x) * 8);
+                    s1 += t.x; s2 += t.y;
+                }
+                const float mean = s1 * (1.f / 64.f);
+                const float var = fmaxf(fmaf(-mean, mean, s2 * (1.f / 64.f)), 0.f);      // biased variance, as nn.GroupNorm
+                const float rstd = rsqrtf(var + a.gn_eps);
+                const float gt[4] = {bf_lo(gn_g[blk].x), bf_hi(gn_g[blk].x), bf_lo(gn_g[blk].y), bf_hi(gn_g[blk].y)};
+                float o[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) o[qq] = fmaf((gn_y[blk][qq] - mean) * rstd, gn_ga[qq], gn_be[qq]) * gt[qq];
+                buf_store8(rs_out, gn_off[blk], make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
+                const int p = grp * GRP + blk * BLK + x;
+                if (a.gn_stats && wv == 0 && g == 0 && p < ntok) {
+                    float* const sp = a.gn_stats + (((long)b * a.T + tokmap(p, REV_Y)) * a.H + h) * 2;
+                    sp[0] = mean; sp[1] = rstd;
+                }
+            }
+        };
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
             WKV6_T(ts0);
@@ -279,11 +322,14 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             // body for tools/check_unrolled_fwd.sh (the wrong y that build once produced was the mixed-shape
             // MFMA accumulation hazard, not a reordered LDS read).
 #ifdef WKV6_FWD_UNROLL
-            constexpr int nb = NBLK;                              // blocks past the end are neutral (zero-filled operands)
-#pragma unroll
+            constexpr bool unrolled = true;
 #else
-            const int nb = min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
+            constexpr bool unrolled = GN;                         // the GN epilogue keeps per-block values in registers: static indices
 #endif
+            // blocks past the end are neutral (zero-filled operands) in the unrolled form
+            const int nb = unrolled ? NBLK : min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
+            constexpr int unroll_by = unrolled ? NBLK : 1;
+#pragma unroll unroll_by
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
                 if (a.ckpt && (unsigned)(blk * BLK) % ckt == 0) {   // state every ckpt_tok tokens, for the backward kernel (slots past T: dropped)
@@ -332,8 +378,21 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                         const int p = grp * GRP + blk * BLK + x;
                         float o[4] = {yt[0] + yi[0], yt[1] + yi[1], yt[2] + yi[2], yt[3] + yi[3]};
                         if (!ACC && !a.y_f32) {                          // plain store: tokens past the end are dropped by the hardware
-                            buf_store8(rs_y, (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g) * 2u,
-                                       make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
+                            const unsigned off = (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g) * 2u;
+                            const uint2 yb = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                            buf_store8(rs_y, off, yb);                   // (a null y: zero-sized resource, the store is dropped)
+                            if constexpr (GN) {
+                                const float yr[4] = {bf_lo(yb.x), bf_hi(yb.x), bf_lo(yb.y), bf_hi(yb.y)};
+                                gn_off[blk] = off;
+                                gn_g[blk] = buf_load8(rs_gate, off);
+                                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                                for (int qq = 0; qq < 4; ++qq) { gn_y[blk][qq] = yr[qq]; s1 += yr[qq]; s2 = fmaf(yr[qq], yr[qq], s2); }
+                                const float two[4] = {s1, s2, 0.f, 0.f};
+                                const float red = col_reduce(two);       // row 0: sum over this wave's 16 channels, row 2: sum of squares
+                                if ((g & 1) == 0)
+                                    *reinterpret_cast<float*>(gn_stat + (grp & 1) * 2048 + ((wv * NBLK + blk) * 16 + x) * 8 + (g >> 1) * 4) = red;
+                            }
                         } else {
                             const bool valid = p < ntok;
                             const int pc = valid ? p : 0;                // padding lanes still form a legal address
@@ -372,6 +431,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
             __syncthreads();
             WKV6_T(ts2);
             WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1);
+            if constexpr (GN) gn_finish(grp);
         }
         if (a.s_out) {
             const long so_ = ((long)b * a.H + h) * HEAD * HEAD + (long)(16 * wv + x) * HEAD + 8 * g;
@@ -401,13 +461,13 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
     }
 }
 
-template <bool W_RAW, bool STATE_ONLY, bool ACC> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
+template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (size_t)GRP_BYTES;
+    constexpr size_t lds = 2 * (size_t)GRP_BYTES + (GN ? 4096 : 0);
     static LdsAttrOnce attr;                   // per instantiation and device
-    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), lds)) return e;
-    if (a.split) hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), dim3(2 * a.B * a.H), dim3(384), lds, st, a);
-    else hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC>), dim3(a.B * a.H), dim3(512), lds, st, a);
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), lds)) return e;
+    if (a.split) hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), dim3(2 * a.B * a.H), dim3(384), lds, st, a);
+    else hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), dim3(a.B * a.H), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -427,6 +487,10 @@ hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
     a.aux = reinterpret_cast<float*>(g_stamp_buffer);
 #endif
     const bool raw = a.wkind == 1;          // 0: fp32 ew = -exp(w), 1: raw w in bf16, 2: fp32 decay exp(-exp(w))
+    if (a.gn_out) {                         // fused GroupNorm * gate epilogue: the four consumer waves of a head in one workgroup
+        if (a.split || a.accumulate || a.y_f32 || a.zero_tail) return hipErrorNotSupported;
+        return raw ? launch_fwd_variant<true, false, false, true>(a, st) : launch_fwd_variant<false, false, false, true>(a, st);
+    }
     if (a.accumulate) return raw ? launch_fwd_variant<true, false, true>(a, st) : launch_fwd_variant<false, false, true>(a, st);
     return raw ? launch_fwd_variant<true, false, false>(a, st) : launch_fwd_variant<false, false, false>(a, st);
 }

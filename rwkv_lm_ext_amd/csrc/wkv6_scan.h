@@ -79,6 +79,11 @@ struct ScanArgs {
                                       // b / ckpt_segs, and its checkpoints go to that sequence's slots (0 / 1: plain)
     float* dsum;                      // chunked forward / state pass: [B*H][4][64] per-block-slot sums of the (clamped) log2-decays
                                       // over the whole sequence (the segment summaries of the T-split forward), or null
+    // chunked forward with the GroupNorm(H) * gate epilogue of the time-mix block fused into its store (src/model.py:462-468):
+    const void *gn_gate, *gn_gamma, *gn_beta;   // gate [B,T,C], ln_x.weight / bias [C] (I/O type); gn_out != null enables it
+    float gn_eps;
+    void* gn_out;                     // [B,T,C]  GroupNorm_H(y) * gate  (y itself is stored too unless y == null)
+    float* gn_stats;                  // [B*T, H, 2] mean, rstd of every (token, head) for the backward, or null
     int split;                        // chunked kernels, set by the launcher when B*H leaves half the chip idle: two workgroups per
                                       // (batch, head), each with its own producers and half of the consuming waves
 };
@@ -109,5 +114,6 @@ hipError_t launch_chunk_bwd64(const ScanArgs& a, hipStream_t st);     // two-lev
 size_t chunk_ckpt_floats(int B, int T, int H);
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // state recurrence only (s_out, ckpt, dsum)
 int cu_count();
+int want_split(int BH);                      // two workgroups per (batch, head)?  (wkv6_chunk_bwd12.hip)
 
 }  // namespace wkv6

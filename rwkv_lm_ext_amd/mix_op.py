@@ -76,39 +76,50 @@ def ddlerp(x, maa, m=None, shifted0=None, rev_n=None):
     return _DDLerp.apply(x, maa.reshape(-1, x.shape[-1]), m, shifted0, rev_n)
 
 
+def gn_gate_forward(y, g, gamma, beta, H, eps):
+    """(out, stats): out = GroupNorm_H(y) * g on [rows, C]; stats fp32 [rows, H, 2] = mean, rstd (for gn_gate_backward)."""
+    y, g, gamma, beta = _require(y, "y"), _require(g, "g"), _require(gamma, "gamma"), _require(beta, "beta")
+    C = y.shape[-1]
+    rows = y.numel() // C
+    out = torch.empty_like(y)
+    stats = torch.empty((rows, H, 2), device=y.device, dtype=torch.float32)
+    with torch.cuda.device(y.device):
+        rc = _lib.load().wkv6_gn_gate_forward(rows, C, H, _ptr(y), _ptr(g), _ptr(gamma), _ptr(beta), float(eps),
+                                              _ptr(out), _ptr(stats), _stream_ptr())
+    _lib.check(rc, "gn_gate forward")
+    return out, stats
+
+
+def gn_gate_backward(y, g, gamma, beta, stats, dout, H):
+    """(dy, dg, dgamma, dbeta) of gn_gate_forward; the parameter gradients are summed from fp32 per-workgroup partial rows."""
+    dout = _require(dout, "dout")
+    C = y.shape[-1]
+    rows = y.numel() // C
+    nparts = min(_NPARTS, rows)
+    dy, dg = torch.empty_like(y), torch.empty_like(g)
+    pg = torch.empty((nparts, C), device=y.device, dtype=torch.float32)
+    pb = torch.empty((nparts, C), device=y.device, dtype=torch.float32)
+    with torch.cuda.device(y.device):
+        rc = _lib.load().wkv6_gn_gate_backward(rows, C, H, _ptr(y), _ptr(g), _ptr(gamma), _ptr(beta), _ptr(stats),
+                                               _ptr(dout), _ptr(dy), _ptr(dg), _ptr(pg), _ptr(pb), nparts, _stream_ptr())
+    _lib.check(rc, "gn_gate backward")
+    return dy, dg, pg.sum(0).to(gamma.dtype), pb.sum(0).to(beta.dtype)
+
+
 class _GroupNormGate(torch.autograd.Function):
     """out = GroupNorm_H(y) * g  on [rows, C] with C = 64 H."""
 
     @staticmethod
     def forward(ctx, y, g, gamma, beta, H, eps):
-        y, g, gamma, beta = _require(y, "y"), _require(g, "g"), _require(gamma, "gamma"), _require(beta, "beta")
-        C = y.shape[-1]
-        rows = y.numel() // C
-        out = torch.empty_like(y)
-        stats = torch.empty((rows, H, 2), device=y.device, dtype=torch.float32)
-        with torch.cuda.device(y.device):
-            rc = _lib.load().wkv6_gn_gate_forward(rows, C, H, _ptr(y), _ptr(g), _ptr(gamma), _ptr(beta), float(eps),
-                                                  _ptr(out), _ptr(stats), _stream_ptr())
-        _lib.check(rc, "gn_gate forward")
-        ctx.save_for_backward(y, g, gamma, beta, stats)
+        out, stats = gn_gate_forward(y, g, gamma, beta, H, eps)
+        ctx.save_for_backward(_require(y, "y"), _require(g, "g"), gamma, beta, stats)
         ctx.H = H
         return out
 
     @staticmethod
     def backward(ctx, dout):
         y, g, gamma, beta, stats = ctx.saved_tensors
-        dout = _require(dout, "dout")
-        C = y.shape[-1]
-        rows = y.numel() // C
-        nparts = min(_NPARTS, rows)
-        dy, dg = torch.empty_like(y), torch.empty_like(g)
-        pg = torch.empty((nparts, C), device=y.device, dtype=torch.float32)
-        pb = torch.empty((nparts, C), device=y.device, dtype=torch.float32)
-        with torch.cuda.device(y.device):
-            rc = _lib.load().wkv6_gn_gate_backward(rows, C, ctx.H, _ptr(y), _ptr(g), _ptr(gamma), _ptr(beta), _ptr(stats),
-                                                   _ptr(dout), _ptr(dy), _ptr(dg), _ptr(pg), _ptr(pb), nparts, _stream_ptr())
-        _lib.check(rc, "gn_gate backward")
-        return dy, dg, pg.sum(0).to(gamma.dtype), pb.sum(0).to(beta.dtype), None, None
+        return gn_gate_backward(y, g, gamma, beta, stats, dout, ctx.H) + (None, None)
 
 
 def group_norm_gate(y, g, gamma, beta, n_head, eps):

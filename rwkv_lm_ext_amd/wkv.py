@@ -96,6 +96,51 @@ class WKV_6_REV(torch.autograd.Function):
             return (None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (ctx.H, ctx.C // ctx.H)), None, None)
 
 
+class WKV_6_GN(torch.autograd.Function):
+    """WKV_6 followed by the time-mix block's `ln_x` GroupNorm(H) and gate multiply (src/model.py:462-468) in ONE forward kernel
+    (SURVEY.md 8f row n1): out = GroupNorm_H(WKV6(r,k,v,w,u); gamma, beta, eps) * g.  The operator's output y makes no round trip
+    through HBM on the way to the normalisation; when no backward follows it is not written at all.  Backward = the GroupNorm /
+    gate backward kernel (mix_op) feeding the operator's backward."""
+
+    @staticmethod
+    def forward(ctx, B, T, C, H, r, k, v, w, u, g, gamma, beta, eps):
+        with torch.no_grad():
+            _assert_inputs(C, H, r, k, v, w, u)
+            train = any(ctx.needs_input_grad)
+            ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if _keep_ckpt(ctx) else None
+            g = g.contiguous()
+            res = wkv6_op.forward_gn_ex(r, k, v, w, u, H, g, gamma, beta, eps, ckpt=ckpt, want_y=train, want_stats=train)
+            ctx.fused = res is not None
+            if res is None:                                    # the library cannot fuse this shape: the two kernels
+                from . import mix_op
+                y = wkv6_op.forward_ex(r, k, v, w, u, H, ckpt=ckpt)
+                out, stats = mix_op.gn_gate_forward(y.view(B * T, C), g.view(B * T, C), gamma, beta, H, eps)
+                out = out.view(B, T, C)
+            else:
+                out, y, stats = res
+            ctx.H, ctx.C, ctx.ckpt = H, C, ckpt
+            if train:
+                ctx.save_for_backward(r, k, v, w, u, g, gamma, beta, y, stats)
+            return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        with torch.no_grad():
+            from . import mix_op
+            r, k, v, w, u, g, gamma, beta, y, stats = ctx.saved_tensors
+            B, T, C = r.shape
+            dy, dg, dgamma, dbeta = mix_op.gn_gate_backward(y.view(B * T, C), g.view(B * T, C), gamma, beta, stats,
+                                                            dout.contiguous().view(B * T, C), ctx.H)
+            gr, gk, gv, gw, gu, _ = wkv6_op.backward_ex(r, k, v, w, u, dy.view(B, T, C), ctx.H, ckpt=ctx.ckpt)
+            ctx.ckpt = None
+            gu = _sum_bf16(gu, (ctx.H, ctx.C // ctx.H))
+            return (None, None, None, None, gr, gk, gv, gw, gu, dg.view(B, T, C), dgamma, dbeta, None)
+
+
+def RUN_CUDA_RWKV6_GN(B, T, C, H, r, k, v, w, u, g, gamma, beta, eps):
+    return WKV_6_GN.apply(B, T, C, H, r, k, v, w, u, g, gamma, beta, eps)
+
+
 def RUN_CUDA_RWKV6(B, T, C, H, r, k, v, w, u):
     return WKV_6.apply(B, T, C, H, r, k, v, w, u)
 

@@ -242,6 +242,29 @@ def forward_ex(r, k, v, w, u, H, s0=None, s_out=None, w_is_ew=False, y=None, alg
     return y
 
 
+def forward_gn_ex(r, k, v, w, u, H, gate, gamma, beta, eps, ckpt=None, want_y=True, want_stats=True):
+    """The operator with the time-mix block's GroupNorm(H) * gate epilogue fused into its store (src/model.py:462-468, SURVEY.md
+    row n1).  Returns (out, y or None, stats or None), or None where the library cannot fuse (so few (batch, head) pairs that
+    two workgroups share one): the caller then runs the two kernels."""
+    B, T, C = r.shape
+    bf = torch.bfloat16
+    btc = (B, T, C)
+    named = dict(r=(r, btc, bf), k=(k, btc, bf), v=(v, btc, bf), w=(w, btc, bf), u=(u, (H, HEAD_SIZE), bf),
+                 gate=(gate, btc, bf), gamma=(gamma, (C,), bf), beta=(beta, (C,), bf))
+    dev = _check_tensors(B, T, C, H, named, dtype=bf)
+    out = torch.empty(btc, device=dev, dtype=bf)
+    y = torch.empty(btc, device=dev, dtype=bf) if want_y else None
+    stats = torch.empty((B * T, H, 2), device=dev, dtype=torch.float32) if want_stats else None
+    with torch.cuda.device(dev):
+        rc = _lib.load().wkv6_forward_gn_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), None, None, _ptr(y),
+                                            _ptr(ckpt), 0 if ckpt is None else ckpt.numel(), _ptr(gate), _ptr(gamma), _ptr(beta),
+                                            float(eps), _ptr(out), _ptr(stats), _lib.W_RAW, _stream_ptr())
+    if rc == _lib.EUNSUPPORTED:
+        return None
+    _lib.check(rc, "wkv6 forward_gn_ex")
+    return out, y, stats
+
+
 def backward_ex(r, k, v, w, u, gy, H, s0=None, w_is_ew=False, want_gs=False, algo=None, ckpt=None):
     """Returns (gr, gk, gv, gw, gu[B,C], gs[B,H,N,N] or None): gradients in the I/O type of `r`, the per-batch partials gu / gs
     in fp32 (WKV6_PARTIALS_F32)."""

@@ -178,3 +178,70 @@ def test_time_mix_module_fused_matches_reference_vectors_and_unfused():
     for n in grads[0]:
         e = max_norm_err(grads[0][n].numpy(), grads[1][n].numpy())
         assert e <= 8e-2, (n, e)          # a bf16 pipeline of ~12 ops (GEMMs, WKV, fused stages) against fp32
+
+
+@pytest.mark.parametrize("shape", [(5, 200, 32), (2, 129, 64), (3, 17, 2)], ids=["B5T200H32", "B2T129H64", "B3T17H2"])
+def test_group_norm_gate_fused_into_the_operator_forward(shape, monkeypatch):
+    """WKV_6_GN = WKV6 -> GroupNorm(H) -> * gate in one forward kernel, against the two-kernel path
+    (WKV_6 + mix_op.group_norm_gate) on the same inputs: the statistics are taken of the same bf16-rounded y, so the outputs agree
+    to one bf16 ulp (the per-head sums run in a different order) and the gradients likewise; without grad no y is written."""
+    from rwkv_lm_ext_amd import wkv, wkv6_op
+    monkeypatch.setenv("WKV6_SPLIT", "0")                     # (few heads would otherwise fall back to the two kernels)
+    B, T, H = shape
+    C = 64 * H
+    mk = lambda *s, scale=1.0, seed=0: rnd(*s, scale=scale, seed=seed).requires_grad_(True)
+    r, k, v, g = mk(B, T, C, scale=0.5, seed=1), mk(B, T, C, scale=0.5, seed=2), mk(B, T, C, scale=0.5, seed=3), mk(B, T, C, seed=4)
+    w = (rnd(B, T, C, scale=0.5, seed=5) - 1.0).detach().requires_grad_(True)
+    u = mk(H, 64, scale=0.3, seed=6)
+    gamma, beta = (rnd(C, scale=0.2, seed=7) + 1.0).detach().requires_grad_(True), mk(C, scale=0.1, seed=8)
+    eps, dout = 64e-5, rnd(B, T, C, seed=9)
+    leaves = (r, k, v, w, u, g, gamma, beta)
+    out_f = wkv.RUN_CUDA_RWKV6_GN(B, T, C, H, r, k, v, w, u, g, gamma, beta, eps)
+    out_f.backward(dout)
+    got = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    y = wkv.RUN_CUDA_RWKV6(B, T, C, H, r, k, v, w, u)
+    out_2 = mix_op_group(y, g, gamma, beta, H, eps)
+    out_2.backward(dout)
+    close(out_f, out_2.float(), "fused out vs two kernels", ulps=1.01, rms=1e-3)
+    for n, a, t in zip(("gr", "gk", "gv", "gw", "gu", "dg", "dgamma", "dbeta"), got, leaves):
+        close(a, t.grad.float(), "fused " + n, ulps=2.02 if n in ("gw", "dgamma", "dbeta", "gu") else 1.5, rms=2e-3)
+    with torch.no_grad():                                       # inference: the same `out`, y is not materialised
+        res = wkv6_op.forward_gn_ex(r, k, v, w, u, H, g, gamma, beta, eps, want_y=False, want_stats=False)
+        assert res is not None and res[1] is None and res[2] is None and torch.equal(res[0], out_f)
+    monkeypatch.setenv("WKV6_SPLIT", "1")                       # two workgroups per head: the library declines, the op falls back
+    with torch.no_grad():
+        assert wkv6_op.forward_gn_ex(r, k, v, w, u, H, g, gamma, beta, eps) is None
+        close(wkv.RUN_CUDA_RWKV6_GN(B, T, C, H, r, k, v, w, u, g, gamma, beta, eps), out_2.float(), "fallback out", ulps=1.01, rms=1e-3)
+
+
+def mix_op_group(y, g, gamma, beta, H, eps):
+    from rwkv_lm_ext_amd import mix_op
+    B, T, C = y.shape
+    return mix_op.group_norm_gate(y.reshape(B * T, C), g.reshape(B * T, C), gamma, beta, H, eps).view(B, T, C)
+
+
+def test_time_mix_module_with_the_fused_epilogue():
+    """callers.Tmix_x060(fuse_epilogue=True): forward and input / parameter gradients against the default two-kernel module."""
+    from oracle import caller_weights as cw
+    from rwkv_lm_ext_amd import callers
+    tm = callers.Tmix_x060(cw.N_EMBD, cw.DIM_ATT)
+    tm.load_state_dict(cw.tmix_weights(torch.Generator().manual_seed(11), layer_id=1), strict=True)
+    tm = tm.cuda().to(bf)
+    os_ = __import__("os")
+    os_.environ["WKV6_SPLIT"] = "0"
+    try:
+        res = {}
+        for fuse in (False, True):
+            tm.fuse_epilogue = fuse
+            x = rnd(3, 40, cw.N_EMBD, seed=31).requires_grad_(True)
+            tm.zero_grad(set_to_none=True)
+            out = tm(x)
+            out.backward(rnd(3, 40, cw.N_EMBD, seed=32))
+            res[fuse] = (out.detach(), x.grad.clone(), tm.ln_x.weight.grad.clone(), tm.time_faaaa.grad.clone())
+    finally:
+        del os_.environ["WKV6_SPLIT"]
+        tm.fuse_epilogue = False
+    for n, a, b in zip(("out", "dx", "d ln_x.weight", "d time_faaaa"), res[True], res[False]):
+        close(a, b.float(), "fused-epilogue module " + n, ulps=2.02, rms=3e-3)
