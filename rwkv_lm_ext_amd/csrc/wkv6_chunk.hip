@@ -276,6 +276,16 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
         const int segs = a.ckpt_segs > 1 ? a.ckpt_segs : 1;
         const long ck_slot0 = ((long)((b / segs) * a.H + h) * segs + b % segs) * nst;
         const rsrc_t rs_ck = make_rsrc(a.ckpt ? a.ckpt + ck_slot0 * (HEAD * HEAD) : nullptr, a.ckpt ? nst * 16384u : 0u);
+        // ACC (second half of wkv6_bi): the addend of a block is requested one block ahead, so that its HBM latency runs under
+        // the previous block's MFMAs instead of in front of the store
+        float acc_old[4] = {0.f, 0.f, 0.f, 0.f};
+        auto acc_fetch = [&](int p) {
+            const int pc = p < ntok ? p : 0;
+            const unsigned idx = (unsigned)(tokmap(pc, REV_Y) * a.C + 16 * wv + 4 * g);
+            if (a.y_f32) io4<float>::load(a.y_f32 + base + idx, acc_old);
+            else io4<bf16_t>::load(gy_ + idx, acc_old);
+        };
+        if constexpr (ACC) acc_fetch(x);
         // GN epilogue state: this group's y (bf16-rounded) and gate per block, the channel's affine parameters
         float gn_y[NBLK][4], gn_ga[4] = {1.f, 1.f, 1.f, 1.f}, gn_be[4] = {0.f, 0.f, 0.f, 0.f};
         uint2 gn_g[NBLK];
@@ -398,11 +408,9 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
                             const int pc = valid ? p : 0;                // padding lanes still form a legal address
                             const unsigned idx = (unsigned)(tokmap(pc, REV_Y) * a.C + 16 * wv + 4 * g);
                             if constexpr (ACC) {
-                                float old[4];
-                                if (a.y_f32) io4<float>::load(a.y_f32 + base + idx, old);
-                                else io4<bf16_t>::load(gy_ + idx, old);
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) o[q] += old[q];
+                                for (int q = 0; q < 4; ++q) o[q] += acc_old[q];      // fetched a block ago
+                                acc_fetch(p + BLK);                                   // the next block's addend: a block's work to arrive
                             }
                             if (valid) {
                                 if (!ACC && a.y_f32) io4<float>::store(a.y_f32 + base + idx, o);

@@ -68,11 +68,13 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
     lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
 }
 
-// GEN = false: gradients are plain bf16 stores (buffer stores, tokens past the end dropped by the hardware): no store-mode
-// branches at all.  GEN = true: the wkv6_bi halves (fp32 side buffers / accumulation) and tail zeroing.  (With the branches in
-// one kernel hipcc merges the "a load may be pending" state of the accumulate path into the plain path and drains the
-// vector-memory queue -- s_waitcnt vmcnt(0) -- around every plain store: backward 0.48 -> 0.58 ms.)
-template <bool W_RAW, bool GEN>
+// GEN = 0: gradients are plain bf16 stores (buffer stores, tokens past the end dropped by the hardware): no store-mode
+// branches at all.  GEN = 1: the first half of wkv6_bi (fp32 side buffers instead of the outputs, tail zeroing) -- stores only.
+// GEN = 2: the second half (adds the first half and rounds once); the addends are requested ahead of the work whose result
+// they meet.  One instantiation each: with the modes as run-time branches of one kernel hipcc merges the "a load may be
+// pending" state of the accumulate path into the other paths and drains the vector-memory queue -- s_waitcnt vmcnt(0) -- around
+// every store (plain backward 0.48 -> 0.58 ms; the first half of wkv6_bi paid the same until it got its own instantiation).
+template <bool W_RAW, int GEN>
 __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][BBLK_BYTES] | checkpoint queue
@@ -106,24 +108,29 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);
     // gradient store of scan position p, channels ch..ch+3: plain; or (wkv6_bi) first half into the fp32 side buffer, second half
     // adds it and rounds once
-    auto emit = [&](int which, const rsrc_t& rs, bf16_t* out, int p, unsigned bit, int ch, float (&o)[4]) {
+    // addend of a second-half store (GEN == 2), to be requested ahead of time: the first half's fp32 side buffer (or the output)
+    auto fetch_old = [&](int which, bf16_t* out, int p, unsigned bit, int ch, float (&old)[4]) {
+        if constexpr (GEN == 2) {
+            const int pc = p < ntok ? p : 0;                         // padding lanes still form a legal address
+            const unsigned idx = (unsigned)(tokmap(pc, bit) * a.C + ch);
+            float* const side = a.g_f32[which];
+            if (side) io4<float>::load(side + base + idx, old);
+            else io4<bf16_t>::load(out + idx, old);
+        }
+    };
+    auto emit = [&](int which, const rsrc_t& rs, bf16_t* out, int p, unsigned bit, int ch, float (&o)[4], const float (&old)[4]) {
         const unsigned idx = (unsigned)(tokmap(p, bit) * a.C + ch);
-        if constexpr (!GEN) {
+        if constexpr (GEN == 0) {
             buf_store8(rs, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
-        } else {
+        } else if constexpr (GEN == 1) {
             if (p >= ntok) return;
             float* const side = a.g_f32[which];
-            if (side && !a.accumulate) {
-                io4<float>::store(side + base + idx, o);
-                return;
-            }
-            if (a.accumulate) {
-                float old[4];
-                if (side) io4<float>::load(side + base + idx, old);
-                else io4<bf16_t>::load(out + idx, old);
+            if (side) io4<float>::store(side + base + idx, o);
+            else io4<bf16_t>::store(out + idx, o);
+        } else {
+            if (p >= ntok) return;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] += old[q];
-            }
+            for (int q = 0; q < 4; ++q) o[q] += old[q];
             io4<bf16_t>::store(out + idx, o);
         }
     };
@@ -408,6 +415,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const bb = buf + blk * BBLK_BYTES;
+                float old_gr[4] = {0.f, 0.f, 0.f, 0.f};
+                fetch_old(0, ogr, grp * STG + blk * BLK + x, REV_R, 16 * wv + 4 * g, old_gr);
                 f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
                 b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: also the B operand of accr
 #pragma unroll
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                         at[blk][q] = rv[q] * dq;
                     }
                     const int p = grp * STG + blk * BLK + x;
-                    emit(0, rs_gr, ogr, p, REV_R, ch, o_gr);
+                    emit(0, rs_gr, ogr, p, REV_R, ch, o_gr, old_gr);
                 }
             }
             WKV6_T(ts3);
@@ -493,6 +502,9 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                 const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
                 const float e16x = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
                 const float e16m8x = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
+                float old_gk[4] = {0.f, 0.f, 0.f, 0.f}, old_gw[4] = {0.f, 0.f, 0.f, 0.f};
+                fetch_old(1, ogk, grp * STG + blk * BLK + x, REV_K, 16 * wv + 4 * g, old_gk);
+                fetch_old(3, ogw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw);
                 // (gy^T Rhat) tiles of the G update: independent of G, issued first so they run under the chain's latency
                 f4v Oi[4];
                 {
@@ -550,8 +562,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                         Rc[q] += total;
                     }
                     const int p = grp * STG + blk * BLK + x;
-                    emit(1, rs_gk, ogk, p, REV_K, ch, o_gk);
-                    emit(3, rs_gw, ogw, p, REV_W, ch, o_gw);
+                    emit(1, rs_gk, ogk, p, REV_K, ch, o_gk, old_gk);
+                    emit(3, rs_gw, ogw, p, REV_W, ch, o_gw, old_gw);
                 }
                 // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
@@ -651,6 +663,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const bb = buf + blk * BBLK_BYTES;
+                float old_gv[4] = {0.f, 0.f, 0.f, 0.f};
+                fetch_old(2, ogv, grp * STG + blk * BLK + x, REV_V, 16 * wv + 4 * g, old_gv);
                 f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -672,7 +686,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
                 {
                     const int p = grp * STG + blk * BLK + x;
                     float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-                    emit(2, rs_gv, ogv, p, REV_V, 16 * wv + 4 * g, o);
+                    emit(2, rs_gv, ogv, p, REV_V, 16 * wv + 4 * g, o, old_gv);
                 }
                 // ---- G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
 #pragma unroll
@@ -711,7 +725,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
         d[7] = rtc1 - rtc0;
     }
 #endif
-    if (GEN && a.zero_tail && !a.accumulate && part == 0) {
+    if (GEN == 1 && a.zero_tail && part == 0) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += (int)(blockDim.x >> 4)) {
             const unsigned idx = (unsigned)(t * a.C + 4 * (tid & 15));
@@ -723,7 +737,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     }
 }
 
-template <bool W_RAW, bool GEN> hipError_t launch_bwd12_inst(const ScanArgs& a, hipStream_t st)
+template <bool W_RAW, int GEN> hipError_t launch_bwd12_inst(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = BWD12_LDS;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -735,8 +749,9 @@ template <bool W_RAW, bool GEN> hipError_t launch_bwd12_inst(const ScanArgs& a, 
 }
 template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStream_t st)
 {
-    const bool gen = a.accumulate || a.zero_tail || a.g_f32[0] || a.g_f32[1] || a.g_f32[2] || a.g_f32[3];
-    return gen ? launch_bwd12_inst<W_RAW, true>(a, st) : launch_bwd12_inst<W_RAW, false>(a, st);
+    if (a.accumulate) return launch_bwd12_inst<W_RAW, 2>(a, st);
+    const bool first_half = a.zero_tail || a.g_f32[0] || a.g_f32[1] || a.g_f32[2] || a.g_f32[3];
+    return first_half ? launch_bwd12_inst<W_RAW, 1>(a, st) : launch_bwd12_inst<W_RAW, 0>(a, st);
 }
 
 }  // namespace
