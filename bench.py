@@ -30,24 +30,84 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI3
 FWD_BYTES, BWD_BYTES = 10, 18   # per token-channel
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_final_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot read PMCs itself, so this is the
-    number measured for the headline workload with the committed kernels; None for any other workload."""
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_final_pmc.json")
+
+
+def pmc_from_file():
+    """Fallback for roofline.traffic / valu_busy: the committed rocprofv3 PMC passes of this round's kernels."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_final_pmc.json")) as f:
-            return int(json.load(f)["kernels"][kernel]["hbm_bytes"])
+        with open(PMC_FILE) as f:
+            return json.load(f)["kernels"]
     except Exception:
-        return None
+        return {}
 
 
-def measured_valu_busy(kernel):
-    """VALU utilisation of the kernel from the same committed PMC file (SURVEY.md 8d asks for it beside the bandwidth figure):
-    SQ_ACTIVE_INST_VALU * 4 / (SIMDs * kernel cycles), with GRBM_GUI_ACTIVE summed over the 8 XCDs."""
+def pmc_live(timeout_s=120):
+    """HBM bytes and VALU utilisation of the two kernels, measured NOW: rank 0 at N = 1 runs this same script as a child under
+    `rocprofv3 --kernel-trace --pmc <group>` (one run per counter group -- FETCH_SIZE and WRITE_SIZE cannot share a pass -- with a
+    handful of fwd+bwd launches each) before it touches the GPU itself, and averages the counters per launch.  FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for gfx950 (KiB units).  Returns {} when rocprofv3 is not usable; the caller then
+    falls back to the committed file and says so in `traffic_source`."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {}
+    acc = {}
+    tmp = tempfile.mkdtemp(prefix="wkv6_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", RWKV_AMD_NO_SELFTEST="1")
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_final_pmc.json")) as f:
-            c = json.load(f)["kernels"][kernel]["counters"]
+        for i, grp in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])):
+            out = os.path.join(tmp, f"g{i}")
+            cmd = [prof, "--kernel-trace", "--pmc", *grp, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return {}
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                per_dispatch = {}                       # a counter of one dispatch may come as several rows: sum them
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        kn = row["Kernel_Name"]
+                        key = "chunk_bwd12_kernel" if "chunk_bwd12" in kn else "chunk_bwd64_kernel" if "chunk_bwd64" in kn else \
+                            "chunk_fwd_kernel" if "chunk_fwd_kernel" in kn else None
+                        if key:
+                            id_ = (key, row["Counter_Name"], row["Dispatch_Id"])
+                            per_dispatch[id_] = per_dispatch.get(id_, 0.0) + float(row["Counter_Value"])
+                for (key, cname, _), val in per_dispatch.items():
+                    acc.setdefault(key, {}).setdefault(cname, []).append(val)
+    except Exception:
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for key, d in acc.items():
+        avg = {c: sum(v) / len(v) for c, v in d.items()}
+        if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+            res[key] = {"counters": avg, "hbm_bytes": int(2 * avg["FETCH_SIZE"] * 1024 + avg["WRITE_SIZE"] * 1024)}
+    return res
+
+
+def pmc_child():
+    """The profiled child of pmc_live(): a few forward + backward launches of the headline workload, nothing else."""
+    from rwkv_lm_ext_amd import wkv6_op
+    dev = torch.device("cuda", 0)
+    B, T, H = 8, 4096, 32
+    r, k, v, w, u, gy = synth(B, T, H, dev)
+    y = torch.empty_like(r)
+    ckpt = wkv6_op.new_checkpoint(B, T, H * 64, H, dev)
+    for _ in range(6):
+        wkv6_op.forward_ex(r, k, v, w, u, H, y=y, ckpt=ckpt)
+        wkv6_op.backward_ex(r, k, v, w, u, gy, H, ckpt=ckpt)
+    torch.cuda.synchronize()
+
+
+def valu_busy_of(c):
+    """SQ_ACTIVE_INST_VALU * 4 / (SIMDs * kernel cycles), GRBM_GUI_ACTIVE being summed over the 8 XCDs."""
+    try:
         return round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3)
     except Exception:
         return None
@@ -158,10 +218,15 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="wkv6", choices=["wkv6", "infctx", "bi", "dp_lora", "prefill"])
+    ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
+                    help="roofline.traffic of the headline workload: measured now under rocprofv3 (N = 1), from the committed PMC file, or omitted")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--layers", type=int, default=24, help="dp_lora: number of RWKV blocks (1B6: 24)")
     ap.add_argument("--per-gpu-batch", type=int, default=32, help="dp_lora: triples per GPU and step")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: spawn the ranks (nothing has touched the GPU yet) and relay
@@ -180,6 +245,12 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the WKV6 operator has no CPU path")
+    pmc, pmc_source = {}, None
+    if args.workload == "wkv6" and rank == 0 and args.traffic != "none":
+        if args.traffic == "live" and world == 1:
+            pmc, pmc_source = pmc_live(), "rocprofv3 --pmc child runs of this invocation"
+        if not pmc:
+            pmc, pmc_source = pmc_from_file(), "profiles/" + os.path.basename(PMC_FILE)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -283,6 +354,8 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         units = tokens * C                                    # token-channels per step per GPU
         dom_name, dom_ms, dom_b = ("backward", bwd_ms, BWD_BYTES) if bwd_ms >= fwd_ms else ("forward", fwd_ms, FWD_BYTES)
+        dom_kernel = "chunk_fwd_kernel" if dom_name == "forward" else \
+            "chunk_bwd64_kernel" if os.environ.get("WKV6_BWD") == "64" else "chunk_bwd12_kernel"
         ach = units * dom_b / (dom_ms * 1e-3) / 1e9
         step_bytes = FWD_BYTES if args.workload == "prefill" else FWD_BYTES + BWD_BYTES
         step_ach = units * step_bytes / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
@@ -303,11 +376,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4),
-                         "traffic": measured_traffic("chunk_bwd12_kernel" if dom_name == "backward" else "chunk_fwd_kernel")
-                         if args.workload == "wkv6" else None,
+                         "traffic": pmc.get(dom_kernel, {}).get("hbm_bytes"),
+                         "traffic_source": pmc_source if pmc.get(dom_kernel) else None,
                          "algorithmic_bytes_per_launch": units * dom_b, "avg_ms": round(dom_ms, 4),
-                         "valu_busy": measured_valu_busy("chunk_bwd12_kernel" if dom_name == "backward" else "chunk_fwd_kernel")
-                         if args.workload == "wkv6" else None},
+                         "valu_busy": valu_busy_of(pmc.get(dom_kernel, {}).get("counters", {}))},
             "roofline_step": {"bound": "hbm", "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(step_ach / HBM_PEAK_GBPS, 4),
                               "algorithmic_bytes": units * step_bytes},

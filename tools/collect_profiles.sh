@@ -1,14 +1,14 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline block refers to.  Run on the GPU box from the repo root:
 #     bash tools/collect_profiles.sh gpurun_out/prof
-# then, back in the container:  python tools/aggregate_profiles.py gpurun_out/prof profiles/r02_final
+# then, back in the container:  python tools/aggregate_profiles.py gpurun_out/prof profiles/r03_final
 # (kernel-trace/stats and every --pmc group are separate runs; no sys/hip trace is combined with --pmc).
 set -e -o pipefail
 OUT=${1:-gpurun_out/prof}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu"
+CMD="python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu --traffic none"   # no nested profiler under the profiler
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats" -- $CMD > "$ROOT/$OUT/stats.log" 2>&1
 i=0
@@ -22,5 +22,7 @@ for wl in bi infctx; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$wl" -- python3 $ROOT/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu > "$ROOT/$OUT/stats_$wl.log" 2>&1 || echo "stats $wl failed"
     python3 $ROOT/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu > "$ROOT/$OUT/bench_$wl.json" 2> /dev/null
 done
-python3 $ROOT/bench.py --steps 100 --warmup 20 > "$ROOT/$OUT/bench_wkv6.json" 2> /dev/null
+python3 $ROOT/bench.py --workload prefill --steps 20 --warmup 5 --no-cpu > "$ROOT/$OUT/bench_prefill.json" 2> /dev/null
+WKV6_BWD=64 python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu > "$ROOT/$OUT/bench_wkv6_bwd64.json" 2> /dev/null   # the opt-in two-level backward
+python3 $ROOT/bench.py --steps 100 --warmup 20 > "$ROOT/$OUT/bench_wkv6.json" 2> "$ROOT/$OUT/bench_wkv6.err"           # traffic measured live
 echo done
