@@ -146,7 +146,8 @@ size_t wkv6bi_kept_bytes(int B, int T, int C, int H);
  * position p < rev_n[b] <-> token rev_n[b]-1-p, exactly reverse_x_idx of src/model_ext.py:410-417); positions >= rev_n[b]
  * keep their place and ARE scanned (the sentence-embedding position sits right behind the reversed span).  WKV6_REV_Y applies
  * to y (written through the map) and, in the backward, to gy; each gradient follows its tensor's bit.  rev_n: int32 [B] on
- * the device.  bf16 I/O, chunked kernels only (WKV6_EUNSUPPORTED with WKV6_IO_F32 / WKV6_ALGO_SCAN).  ckpt may be NULL. */
+ * the device.  bf16 I/O on the chunked kernels; WKV6_IO_F32 / WKV6_ALGO_SCAN run the exact scan kernels with the same index
+ * maps (ckpt is ignored there).  ckpt may be NULL. */
 enum { WKV6_REV_R = 1, WKV6_REV_K = 2, WKV6_REV_V = 4, WKV6_REV_W = 8, WKV6_REV_Y = 16 };
 int wkv6_forward_rev_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v, const void* w,
                         const void* u, void* y, void* ckpt, size_t ckpt_bytes, const int* rev_n, unsigned rev_mask,
@@ -155,6 +156,28 @@ int wkv6_backward_rev_ex(int B, int T, int C, int H, const void* r, const void* 
                          const void* u, const void* gy, void* gr, void* gk, void* gv, void* gw, void* gu,
                          void* workspace, size_t workspace_bytes, const int* rev_n, unsigned rev_mask, unsigned flags,
                          void* stream);
+
+/* ---- both operator calls of a bidirectional time-mix layer in ONE launch (second half): the
+ * forward-direction call and the reversed-direction call of src/model_bi.py:331-348 (composition B: same r, w, reversed k, v, y)
+ * and src/model_ext.py:421-437 (composition C: separately projected, fully reversed) are two problems of one shape; a grid of
+ * 2 B H workgroups serves problem s[0] with its first B H slots and s[1] with the rest -- one launch, one tail.  Each set names its
+ * own tensors, reversal map (rev_n NULL = none) and checkpoint buffer (wkv6_backward_workspace_bytes() bytes each; required by
+ * the backward, which must find them filled by wkv6_forward_pair_ex; may be NULL in a forward nobody differentiates).  u [H,N]
+ * is shared.  bf16 I/O, chunked kernels; flags: WKV6_W_RAW / WKV6_PARTIALS_F32 as elsewhere (WKV6_EUNSUPPORTED with WKV6_IO_F32 /
+ * WKV6_ALGO_SCAN).  Results are bit-identical to two wkv6_forward_rev_ex / wkv6_backward_rev_ex calls. */
+typedef struct wkv6_seq_set {
+    const void *r, *k, *v, *w;          /* [B,T,C] inputs */
+    void* y;                            /* forward: [B,T,C] output */
+    const void* gy;                     /* backward: [B,T,C] */
+    void *gr, *gk, *gv, *gw;            /* backward: [B,T,C] gradients */
+    void* gu;                           /* backward: [B,C] per-batch partials of this problem (bf16, or fp32 with WKV6_PARTIALS_F32) */
+    void* ckpt;                         /* state checkpoints written by the forward, read by the backward */
+    size_t ckpt_bytes;
+    const int* rev_n;                   /* int32 [B] on the device, or NULL */
+    unsigned rev_mask;                  /* WKV6_REV_* */
+} wkv6_seq_set;
+int wkv6_forward_pair_ex(int B, int T, int C, int H, const void* u, const wkv6_seq_set* s, unsigned flags, void* stream);
+int wkv6_backward_pair_ex(int B, int T, int C, int H, const void* u, const wkv6_seq_set* s, unsigned flags, void* stream);
 
 /* ---- elementwise neighbours of the operator in the RWKV-6 time-mix block; bf16 only ----
  * ddlerp (src/model.py:435-448): xx = shift(x) - x; out[s] = x + xx * (maa[s] + m[s]), s < NS.

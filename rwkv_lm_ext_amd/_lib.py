@@ -16,6 +16,12 @@ _F = ctypes.c_float
 _SZ = ctypes.c_size_t
 _U = ctypes.c_uint
 
+class SeqSet(ctypes.Structure):
+    """wkv6_seq_set of include/wkv6_amd.h: one of the two problems of a pair launch."""
+    _fields_ = [("r", _VP), ("k", _VP), ("v", _VP), ("w", _VP), ("y", _VP), ("gy", _VP), ("gr", _VP), ("gk", _VP), ("gv", _VP),
+                ("gw", _VP), ("gu", _VP), ("ckpt", _VP), ("ckpt_bytes", _SZ), ("rev_n", _VP), ("rev_mask", _U)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/wkv6_amd.h
 SIGNATURES = {
     "wkv6_cuda_forward": (_I, [_I] * 4 + [_VP] * 7),
@@ -37,6 +43,8 @@ SIGNATURES = {
     "wkv6_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
     "wkv6_forward_rev_ex": (_I, [_I] * 4 + [_VP] * 7 + [_SZ, _VP, _U, _U, _VP]),
     "wkv6_backward_rev_ex": (_I, [_I] * 4 + [_VP] * 12 + [_SZ, _VP, _U, _U, _VP]),
+    "wkv6_forward_pair_ex": (_I, [_I] * 4 + [_VP, ctypes.POINTER(SeqSet), _U, _VP]),
+    "wkv6_backward_pair_ex": (_I, [_I] * 4 + [_VP, ctypes.POINTER(SeqSet), _U, _VP]),
     "wkv6bi_forward_ex": (_I, [_I] * 4 + [_VP] * 9 + [_SZ, _U, _VP]),
     "wkv6bi_backward_ex": (_I, [_I] * 4 + [_VP] * 14 + [_SZ, _U, _VP]),
     "wkv6_ddlerp_forward": (_I, [_I] * 4 + [_VP] * 6),

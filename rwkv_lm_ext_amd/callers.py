@@ -57,6 +57,9 @@ class Tmix_x060(nn.Module):
         # MI355X: fwd+bwd 6.644 vs 6.626 ms, forward only 1.612 vs 1.593 ms (profiles/r03_tmix_layer_epilogue.txt): the 56 us
         # GroupNorm kernel runs at 5.4 TB/s, and the statistics exchange lengthens the forward's consumer waves by as much.
         self.fuse_epilogue = False
+        # forward_bi_b / forward_bi_c with in-kernel reversal: both operator calls of the layer in one launch per pass
+        # (wkv.WKV_6_PAIR) instead of two
+        self.pair_launch = True
         d_mix = 64 if n_embd == 4096 else 32                              # TIME_MIX_EXTRA_DIM
         d_decay = 128 if n_embd == 4096 else 64                           # TIME_DECAY_EXTRA_DIM
         z = lambda *s: nn.Parameter(torch.zeros(*s))
@@ -155,6 +158,15 @@ class Tmix_x060(nn.Module):
         return WKV_6_REV.apply(B, T, C, self.n_head, *(t.to(bf).contiguous() for t in (r, k, v, w, self.time_faaaa)),
                                rev_n, rev_mask).to(r.dtype)
 
+    def _pair_wkv(self, fwd, rev, rev_n, rev_mask):
+        """Both operator calls of a bidirectional composition in one launch per pass (wkv.WKV_6_PAIR, row n2)."""
+        from .wkv import WKV_6_PAIR
+        B, T, C = fwd[0].shape
+        bf = torch.bfloat16
+        y, ry = WKV_6_PAIR.apply(B, T, C, self.n_head, *(t.to(bf).contiguous() for t in (*fwd, *rev)),
+                                 self.time_faaaa.to(bf).contiguous(), rev_n, rev_mask)
+        return y.to(fwd[0].dtype), ry.to(fwd[0].dtype)
+
     def _in_kernel_reversal(self, x):
         """Rows n2: with the HIP operator on bf16 GPU tensors the reversed half of the bidirectional compositions is
         addressed inside the kernels (wkv6_*_rev_ex, ddlerp rev_n) instead of through torch.gather round trips."""
@@ -163,13 +175,16 @@ class Tmix_x060(nn.Module):
     def forward_bi_c(self, x, rev_idx, mask=None):
         """composition C (src/model_ext.py:421-437): reverse the hidden states, project twice, average."""
         r, k, v, g, w = self.jit_func(x)
-        y = self._run(r, k, v, w)
         if mask is not None and self._in_kernel_reversal(x):
             from .wkv6_op import REV_ALL
             rev_n = mask.sum(dim=1).to(torch.int32)
             rr, rk, rv, _, rw = self.jit_func(x, rev_n=rev_n)      # the reversed stream's projections, in original order
-            ry = self._rev_wkv(rr, rk, rv, rw, rev_n, REV_ALL)
+            if self.pair_launch:
+                y, ry = self._pair_wkv((r, k, v, w), (rr, rk, rv, rw), rev_n, REV_ALL)
+            else:
+                y, ry = self._run(r, k, v, w), self._rev_wkv(rr, rk, rv, rw, rev_n, REV_ALL)
         else:
+            y = self._run(r, k, v, w)
             rr, rk, rv, _, rw = self.jit_func(reverse_x(x, rev_idx))
             ry = reverse_x(self._run(rr, rk, rv, rw), rev_idx)
         return self.jit_func_2((y + ry) / 2, g)
@@ -180,11 +195,15 @@ class Tmix_x060(nn.Module):
         if mask is None:
             mask = torch.ones(B, T, device=x.device)
         r, k, v, g, w = self.jit_func(x)
-        y = self._run(r, k, v, w)
         if self._in_kernel_reversal(x):
             from .wkv6_op import REV_K, REV_V, REV_Y
-            ry = self._rev_wkv(r, k, v, w, mask.sum(dim=1).to(torch.int32), REV_K | REV_V | REV_Y)
+            rev_n = mask.sum(dim=1).to(torch.int32)
+            if self.pair_launch:
+                y, ry = self._pair_wkv((r, k, v, w), (r, k, v, w), rev_n, REV_K | REV_V | REV_Y)
+            else:
+                y, ry = self._run(r, k, v, w), self._rev_wkv(r, k, v, w, rev_n, REV_K | REV_V | REV_Y)
             return self.jit_func_2(y + ry, g)
+        y = self._run(r, k, v, w)
         rev_idx = reverse_x_idx(mask, T)
         ry = self._run(r, reverse_x(k, rev_idx), reverse_x(v, rev_idx), w)
         return self.jit_func_2(y + reverse_x(ry, rev_idx), g)

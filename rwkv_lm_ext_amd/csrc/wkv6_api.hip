@@ -359,13 +359,15 @@ int wkv6_forward_rev_ex(int B, int T, int C, int H, const void* r, const void* k
 {
     if (int rc = check_shape(B, T, C, H)) return rc;
     if (!r || !k || !v || !w || !u || !y || !rev_n) return WKV6_ENULL;
-    if ((flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) || (rev_mask & ~(unsigned)REV_ALL)) return WKV6_EUNSUPPORTED;
+    if (rev_mask & ~(unsigned)REV_ALL) return WKV6_EUNSUPPORTED;
     if (ckpt && ckpt_bytes < wkv6_backward_workspace_bytes(B, T, C, H)) return WKV6_EWORKSPACE;
     ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
     a.y = y;
-    a.ckpt = reinterpret_cast<float*>(ckpt);
     a.rev_n = rev_n;
     a.rev_mask = rev_mask;
+    if (flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN))        // exact scan kernels (fp32 I/O, or forced): same index maps, no checkpoints
+        return to_rc(launch_scan_fwd(a, flags & WKV6_IO_F32, (hipStream_t)stream));
+    a.ckpt = reinterpret_cast<float*>(ckpt);
     return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
 }
 
@@ -376,7 +378,7 @@ int wkv6_backward_rev_ex(int B, int T, int C, int H, const void* r, const void* 
 {
     if (int rc = check_shape(B, T, C, H)) return rc;
     if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw || !rev_n) return WKV6_ENULL;
-    if ((flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) || (rev_mask & ~(unsigned)REV_ALL)) return WKV6_EUNSUPPORTED;
+    if (rev_mask & ~(unsigned)REV_ALL) return WKV6_EUNSUPPORTED;
     const size_t need = wkv6_backward_workspace_bytes(B, T, C, H);
     StreamScratch scratch;                     // released (stream-ordered) when this call returns
     if (!workspace) {
@@ -390,6 +392,46 @@ int wkv6_backward_rev_ex(int B, int T, int C, int H, const void* r, const void* 
     a.rev_n = rev_n;
     a.rev_mask = rev_mask;
     return to_rc(run_bwd(a, flags, reinterpret_cast<float*>(workspace), (hipStream_t)stream));
+}
+
+static int pair_args(int B, int T, int C, int H, const void* u, const wkv6_seq_set* s, unsigned flags, bool bwd, ScanArgs (&a)[2])
+{
+    if (int rc = check_shape(B, T, C, H)) return rc;
+    if (!u || !s) return WKV6_ENULL;
+    if (flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) return WKV6_EUNSUPPORTED;
+    const size_t need = wkv6_backward_workspace_bytes(B, T, C, H);
+    for (int i = 0; i < 2; ++i) {
+        const wkv6_seq_set& q = s[i];
+        if (!q.r || !q.k || !q.v || !q.w) return WKV6_ENULL;
+        if (bwd ? (!q.gy || !q.gr || !q.gk || !q.gv || !q.gw || !q.ckpt) : !q.y) return WKV6_ENULL;
+        if (q.rev_mask & ~(unsigned)REV_ALL) return WKV6_EUNSUPPORTED;
+        if (q.ckpt && q.ckpt_bytes < need) return WKV6_EWORKSPACE;
+        a[i] = base_args(B, T, C, H, q.r, q.k, q.v, q.w, u, flags);
+        a[i].ckpt = reinterpret_cast<float*>(q.ckpt);
+        a[i].rev_n = q.rev_n;
+        a[i].rev_mask = q.rev_n ? q.rev_mask : 0u;
+        if (bwd) {
+            a[i].gy = q.gy; a[i].gr = q.gr; a[i].gk = q.gk; a[i].gv = q.gv; a[i].gw = q.gw; a[i].gu = q.gu;
+            a[i].ckpt_valid = 1;
+        } else {
+            a[i].y = q.y;
+        }
+    }
+    return WKV6_OK;
+}
+
+int wkv6_forward_pair_ex(int B, int T, int C, int H, const void* u, const wkv6_seq_set* s, unsigned flags, void* stream)
+{
+    ScanArgs a[2];
+    if (int rc = pair_args(B, T, C, H, u, s, flags, false, a)) return rc;
+    return to_rc(launch_chunk_fwd_pair(a[0], a[1], (hipStream_t)stream));
+}
+
+int wkv6_backward_pair_ex(int B, int T, int C, int H, const void* u, const wkv6_seq_set* s, unsigned flags, void* stream)
+{
+    ScanArgs a[2];
+    if (int rc = pair_args(B, T, C, H, u, s, flags, true, a)) return rc;
+    return to_rc(launch_chunk_bwd_pair(a[0], a[1], (hipStream_t)stream));
 }
 
 int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,

@@ -48,8 +48,10 @@ constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 // store epilogue: a token's statistics span the head's 64 channels = the four consumer waves, which exchange their 16-channel
 // sums (of the bf16-rounded y, what nn.GroupNorm would see) through LDS at the group barrier the kernel has anyway and write
 // GroupNorm_H(y) * gate one group later from the y they kept in registers; y makes no round trip through HBM.
+// The kernel proper is a device function of (arguments, workgroup slot): chunk_fwd_kernel runs it on its one argument block,
+// chunk_fwd_pair_kernel (the two WKV problems of a bidirectional composition in ONE launch) on one of two.
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false>
-__global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
+__device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
     // of the four consumers (value columns [32 part, 32 part + 32)): hardware wave w plays consumer 2 part + w for w < 2 and
     // producer w - 2 (wave id 4 + w - 2) otherwise.  The preparation is duplicated, on CUs that would otherwise idle.
     const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform, provably so
-    const int part = a.split ? (int)(blockIdx.x & 1) : 0, bh = a.split ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int part = a.split ? (int)(slot & 1) : 0, bh = a.split ? (int)(slot >> 1) : (int)slot;
     const int wid = a.split ? (hwid < 2 ? 2 * part + hwid : hwid + 2) : hwid;
     const bool producer = wid >= 4;
     const int wv = wid & 3;                                          // block (producer) / column tile (consumer)
@@ -469,6 +471,22 @@ __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
     }
 }
 
+template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false>
+__global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
+{
+    chunk_fwd_body<W_RAW, STATE_ONLY, ACC, GN>(a, blockIdx.x);
+}
+
+// Two problems of the same shape in one grid of 2 B H workgroups: slots [0, B H) serve a0, the rest a1 (src/model_bi.py:331-348,
+// src/model_ext.py:421-437: the forward-direction and the reversed-direction operator calls of a bidirectional time-mix layer).
+template <bool W_RAW>
+__global__ __launch_bounds__(512) void chunk_fwd_pair_kernel(const ScanArgs a0, const ScanArgs a1)
+{
+    const unsigned n = (unsigned)(a0.B * a0.H);
+    const bool second = blockIdx.x >= n;                      // workgroup-uniform: the argument block is read through one of two
+    chunk_fwd_body<W_RAW, false, false, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);   // kernarg addresses
+}
+
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = 2 * (size_t)GRP_BYTES + (GN ? 4096 : 0);
@@ -501,6 +519,32 @@ hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
     }
     if (a.accumulate) return raw ? launch_fwd_variant<true, false, true>(a, st) : launch_fwd_variant<false, false, true>(a, st);
     return raw ? launch_fwd_variant<true, false, false>(a, st) : launch_fwd_variant<false, false, false>(a, st);
+}
+
+// Both problems of a bidirectional composition in one launch (same shape and decay kind; checkpoints optional).  Falls back to
+// two launches where one (batch, head) is split over two workgroups.
+hipError_t launch_chunk_fwd_pair(const ScanArgs& a0_, const ScanArgs& a1_, hipStream_t st)
+{
+    if (!offsets_fit(a0_) || !offsets_fit(a1_)) return hipErrorInvalidValue;
+    if (a0_.B != a1_.B || a0_.T != a1_.T || a0_.C != a1_.C || a0_.H != a1_.H || a0_.wkind != a1_.wkind) return hipErrorInvalidValue;
+    const auto plain = [](const ScanArgs& a) { return !a.accumulate && !a.y_f32 && !a.zero_tail && !a.gn_out && !a.dsum && !a.ckpt_segs; };
+    if (!plain(a0_) || !plain(a1_)) return hipErrorNotSupported;
+    if (want_split(a0_.B * a0_.H)) {
+        if (hipError_t e = launch_chunk_fwd(a0_, st)) return e;
+        return launch_chunk_fwd(a1_, st);
+    }
+    ScanArgs a0 = a0_, a1 = a1_;
+    a0.split = a1.split = 0;
+    constexpr size_t lds = 2 * (size_t)GRP_BYTES;
+    static LdsAttrOnce attr_raw, attr_ew;
+    if (a0.wkind == 1) {
+        if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_fwd_pair_kernel<true>), lds)) return e;
+        hipLaunchKernelGGL((chunk_fwd_pair_kernel<true>), dim3(2 * a0.B * a0.H), dim3(512), lds, st, a0, a1);
+    } else {
+        if (hipError_t e = attr_ew.ensure(reinterpret_cast<const void*>(chunk_fwd_pair_kernel<false>), lds)) return e;
+        hipLaunchKernelGGL((chunk_fwd_pair_kernel<false>), dim3(2 * a0.B * a0.H), dim3(512), lds, st, a0, a1);
+    }
+    return hipGetLastError();
 }
 
 // state recurrence only, dumping the stage-entry states into a.ckpt (first half of the self-contained backward)

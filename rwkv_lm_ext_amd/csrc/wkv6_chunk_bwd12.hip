@@ -74,8 +74,10 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 // they meet.  One instantiation each: with the modes as run-time branches of one kernel hipcc merges the "a load may be
 // pending" state of the accumulate path into the other paths and drains the vector-memory queue -- s_waitcnt vmcnt(0) -- around
 // every store (plain backward 0.48 -> 0.58 ms; the first half of wkv6_bi paid the same until it got its own instantiation).
+// (The kernel proper is a device function of (arguments, workgroup slot) so that chunk_bwd12_pair_kernel can run it on one of two
+// argument blocks: SURVEY.md row n2.)
 template <bool W_RAW, int GEN>
-__global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
+__device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsigned slot)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][BBLK_BYTES] | checkpoint queue
     const int tid = threadIdx.x, lane = tid & 63;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     // otherwise idle CUs); hardware wave w of workgroup part p plays wave w (p = 0) / 4 + w (p = 1) for w < 4 and producer
     // 8 + (w - 4) for w >= 4.
     const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int part = a.split ? (int)(blockIdx.x & 1) : 0, bh = a.split ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int part = a.split ? (int)(slot & 1) : 0, bh = a.split ? (int)(slot >> 1) : (int)slot;
     const int wid = a.split ? (hwid < 4 ? hwid + 4 * part : hwid + 4) : hwid;
     const bool rowrole = wid < 4, producer = wid >= 8;
     const int wv = wid & 3;                                              // tile owned by a row / column wave
@@ -737,6 +739,21 @@ __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
     }
 }
 
+template <bool W_RAW, int GEN>
+__global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
+{
+    chunk_bwd12_body<W_RAW, GEN>(a, blockIdx.x);
+}
+
+// the backward of chunk_fwd_pair_kernel (wkv6_chunk.hip): two problems of one shape, slots [0, B H) serve a0, the rest a1
+template <bool W_RAW>
+__global__ __launch_bounds__(768) void chunk_bwd12_pair_kernel(const ScanArgs a0, const ScanArgs a1)
+{
+    const unsigned n = (unsigned)(a0.B * a0.H);
+    const bool second = blockIdx.x >= n;
+    chunk_bwd12_body<W_RAW, 0>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);
+}
+
 template <bool W_RAW, int GEN> hipError_t launch_bwd12_inst(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = BWD12_LDS;
@@ -808,6 +825,34 @@ hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)
 #else
     return a.wkind ? launch_bwd12_variant<true>(a, st) : launch_bwd12_variant<false>(a, st);
 #endif
+}
+
+// Backward of both problems of a bidirectional composition in one launch; both checkpoint sets must come from the forward
+// (ckpt_valid).  Two launches where a (batch, head) pair is split over two workgroups or the two-level kernel is selected.
+hipError_t launch_chunk_bwd_pair(const ScanArgs& a0_, const ScanArgs& a1_, hipStream_t st)
+{
+    if (a0_.B != a1_.B || a0_.T != a1_.T || a0_.C != a1_.C || a0_.H != a1_.H || a0_.wkind != a1_.wkind) return hipErrorInvalidValue;
+    const auto plain = [](const ScanArgs& a) {
+        return !a.accumulate && !a.zero_tail && !a.g_f32[0] && !a.g_f32[1] && !a.g_f32[2] && !a.g_f32[3] && a.ckpt && a.ckpt_valid;
+    };
+    if (!plain(a0_) || !plain(a1_)) return hipErrorNotSupported;
+    if (a0_.ckpt_tok != STG || a1_.ckpt_tok != STG || want_split(a0_.B * a0_.H)) {
+        if (hipError_t e = launch_chunk_bwd(a0_, st)) return e;
+        return launch_chunk_bwd(a1_, st);
+    }
+    if (a0_.wkind != 1 && ((long)a0_.T + 64) * a0_.C >= (1L << 30)) return hipErrorInvalidValue;
+    ScanArgs a0 = a0_, a1 = a1_;
+    a0.split = a1.split = 0;
+    constexpr size_t lds = BWD12_LDS;
+    static LdsAttrOnce attr_raw, attr_ew;
+    if (a0.wkind == 1) {
+        if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_bwd12_pair_kernel<true>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12_pair_kernel<true>), dim3(2 * a0.B * a0.H), dim3(768), lds, st, a0, a1);
+    } else {
+        if (hipError_t e = attr_ew.ensure(reinterpret_cast<const void*>(chunk_bwd12_pair_kernel<false>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12_pair_kernel<false>), dim3(2 * a0.B * a0.H), dim3(768), lds, st, a0, a1);
+    }
+    return hipGetLastError();
 }
 
 }  // namespace wkv6

@@ -108,6 +108,9 @@ hipError_t launch_scan_bwd(const ScanArgs& a, bool io_f32, hipStream_t st);
 hipError_t launch_selftest(int* result, hipStream_t st);
 // chunked MFMA forward (bf16 I/O only), wkv6_chunk.hip
 hipError_t launch_chunk_fwd(const ScanArgs& a, hipStream_t st);
+// two problems of one shape in one launch; the backward needs both problems' forward checkpoints
+hipError_t launch_chunk_fwd_pair(const ScanArgs& a0, const ScanArgs& a1, hipStream_t st);
+hipError_t launch_chunk_bwd_pair(const ScanArgs& a0, const ScanArgs& a1, hipStream_t st);
 // chunked MFMA backward (bf16 I/O only): state pass + reverse pass; a.ckpt must hold chunk_ckpt_floats() floats
 hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st);
 hipError_t launch_chunk_bwd64(const ScanArgs& a, hipStream_t st);     // two-level backward proper (wkv6_chunk_bwd64.hip)

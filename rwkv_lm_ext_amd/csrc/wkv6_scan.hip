@@ -109,6 +109,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanArgs a)
     T* const gy_ = reinterpret_cast<T*>(a.y);
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
+    const RevMap tokmap = make_revmap(a, b, ntok);      // token each tensor holds at scan position p (wkv6_scan.h)
     const long base = (long)b * a.T * a.C + (long)h * HEAD;
 
     // staging role
@@ -138,16 +139,17 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanArgs a)
     auto load_regs = [&](int q) {
         const int p = q * TB + spp;
         const bool valid = p < ntok;
-        const int t = a.reverse ? ntok - 1 - p : p;
-        const long idx = base + (long)t * a.C + sc0;
+        [[maybe_unused]] const long idx_r = base + (long)tokmap(p, REV_R) * a.C + sc0, idx_k = base + (long)tokmap(p, REV_K) * a.C + sc0;
+        [[maybe_unused]] const long idx_v = base + (long)tokmap(p, REV_V) * a.C + sc0, idx_w = base + (long)tokmap(p, REV_W) * a.C + sc0;
+        [[maybe_unused]] const long idx_y = base + (long)tokmap(p, REV_Y) * a.C + sc0, idx_p = base + (long)p * a.C + sc0;   // idx_p: scratch indexed by scan position
 #pragma unroll
         for (int c = 0; c < CPT; ++c) { pr[c] = 0.f; pk[c] = 0.f; pv[c] = 0.f; }
         if (valid) {
-            ion<T, CPT>::load(gr_ + idx, pr);
-            ion<T, CPT>::load(gk_ + idx, pk);
-            ion<T, CPT>::load(gv_ + idx, pv);
+            ion<T, CPT>::load(gr_ + idx_r, pr);
+            ion<T, CPT>::load(gk_ + idx_k, pk);
+            ion<T, CPT>::load(gv_ + idx_v, pv);
         }
-        load_ew<T, CPT>(a, idx, valid, pew);
+        load_ew<T, CPT>(a, idx_w, valid, pew);
     };
     auto write_lds = [&](int buf) {
         float* const ib_ = inb + buf * 4 * TB * ROW + spp * ROW + sc0;
@@ -211,19 +213,20 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanArgs a)
         {   // ---- coalesced store of this batch's outputs
             const int p = q * TB + spp;
             if (p < ntok) {
-                const int t = a.reverse ? ntok - 1 - p : p;
-                const long idx = base + (long)t * a.C + sc0;
+                [[maybe_unused]] const long idx_r = base + (long)tokmap(p, REV_R) * a.C + sc0, idx_k = base + (long)tokmap(p, REV_K) * a.C + sc0;
+                [[maybe_unused]] const long idx_v = base + (long)tokmap(p, REV_V) * a.C + sc0, idx_w = base + (long)tokmap(p, REV_W) * a.C + sc0;
+                [[maybe_unused]] const long idx_y = base + (long)tokmap(p, REV_Y) * a.C + sc0, idx_p = base + (long)p * a.C + sc0;   // idx_p: scratch indexed by scan position
                 float o[CPT];
                 lds_load<CPT>(ys + buf * TB * ROW + spp * ROW + sc0, o);
                 if (a.accumulate) {
                     float old[CPT];
-                    if (a.y_f32) lds_load<CPT>(a.y_f32 + idx, old);
-                    else ion<T, CPT>::load(gy_ + idx, old);
+                    if (a.y_f32) lds_load<CPT>(a.y_f32 + idx_y, old);
+                    else ion<T, CPT>::load(gy_ + idx_y, old);
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) o[c] += old[c];
                 }
-                if (a.y_f32 && !a.accumulate) lds_store<CPT>(a.y_f32 + idx, o);
-                else ion<T, CPT>::store(gy_ + idx, o);
+                if (a.y_f32 && !a.accumulate) lds_store<CPT>(a.y_f32 + idx_y, o);
+                else ion<T, CPT>::store(gy_ + idx_y, o);
             }
         }
     }
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_s_kernel(const ScanArgs a)
     T* const ogr = reinterpret_cast<T*>(a.gr);
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
+    const RevMap tokmap = make_revmap(a, b, ntok);      // token each tensor holds at scan position p (wkv6_scan.h)
     const long base = (long)b * a.T * a.C + (long)h * HEAD;
 
     const int spp = tid / TPT, sc0 = (tid % TPT) * CPT;
@@ -299,17 +303,18 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_s_kernel(const ScanArgs a)
     auto load_regs = [&](int q) {
         const int p = q * TB + spp;
         const bool valid = p < ntok;
-        const int t = a.reverse ? ntok - 1 - p : p;
-        const long idx = base + (long)t * a.C + sc0;
+        [[maybe_unused]] const long idx_r = base + (long)tokmap(p, REV_R) * a.C + sc0, idx_k = base + (long)tokmap(p, REV_K) * a.C + sc0;
+        [[maybe_unused]] const long idx_v = base + (long)tokmap(p, REV_V) * a.C + sc0, idx_w = base + (long)tokmap(p, REV_W) * a.C + sc0;
+        [[maybe_unused]] const long idx_y = base + (long)tokmap(p, REV_Y) * a.C + sc0, idx_p = base + (long)p * a.C + sc0;   // idx_p: scratch indexed by scan position
 #pragma unroll
         for (int c = 0; c < CPT; ++c) { pr[c] = 0.f; pk[c] = 0.f; pv[c] = 0.f; pgy[c] = 0.f; }
         if (valid) {
-            ion<T, CPT>::load(gr_ + idx, pr);
-            ion<T, CPT>::load(gk_ + idx, pk);
-            ion<T, CPT>::load(gv_ + idx, pv);
-            ion<T, CPT>::load(ggy + idx, pgy);
+            ion<T, CPT>::load(gr_ + idx_r, pr);
+            ion<T, CPT>::load(gk_ + idx_k, pk);
+            ion<T, CPT>::load(gv_ + idx_v, pv);
+            ion<T, CPT>::load(ggy + idx_y, pgy);
         }
-        load_ew<T, CPT>(a, idx, valid, pew);
+        load_ew<T, CPT>(a, idx_w, valid, pew);
     };
     auto write_lds = [&](int buf) {
         float* const ib_ = inb + buf * 4 * TB * ROW + spp * ROW + sc0;
@@ -376,8 +381,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_s_kernel(const ScanArgs a)
         {
             const int p = q * TB + spp;
             if (p < ntok) {
-                const int t = a.reverse ? ntok - 1 - p : p;
-                const long idx = base + (long)t * a.C + sc0;
+                [[maybe_unused]] const long idx_r = base + (long)tokmap(p, REV_R) * a.C + sc0, idx_k = base + (long)tokmap(p, REV_K) * a.C + sc0;
+                [[maybe_unused]] const long idx_v = base + (long)tokmap(p, REV_V) * a.C + sc0, idx_w = base + (long)tokmap(p, REV_W) * a.C + sc0;
+                [[maybe_unused]] const long idx_y = base + (long)tokmap(p, REV_Y) * a.C + sc0, idx_p = base + (long)p * a.C + sc0;   // idx_p: scratch indexed by scan position
                 float dq[CPT], av[CPT], o[CPT];
                 lds_load<CPT>(dqs + buf * TB * ROW + spp * ROW + sc0, dq);
 #pragma unroll
@@ -385,14 +391,14 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_s_kernel(const ScanArgs a)
                     av[c] = cr[c] * dq[c];
                     o[c] = fmaf(uu[c] * ck[c], cvg, dq[c]);
                 }
-                lds_store<CPT>(a.aux + idx, av);       // plain (global) vector store
+                lds_store<CPT>(a.aux + idx_p, av);       // plain (global) vector store
                 if (a.accumulate) {
                     float old[CPT];
-                    ion<T, CPT>::load(ogr + idx, old);
+                    ion<T, CPT>::load(ogr + idx_r, old);
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) o[c] += old[c];
                 }
-                ion<T, CPT>::store(ogr + idx, o);
+                ion<T, CPT>::store(ogr + idx_r, o);
             }
         }
     }
@@ -442,6 +448,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_g_kernel(const ScanArgs a)
     T* const ogw = reinterpret_cast<T*>(a.gw);
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
+    const RevMap tokmap = make_revmap(a, b, ntok);      // token each tensor holds at scan position p (wkv6_scan.h)
     const long base = (long)b * a.T * a.C + (long)h * HEAD;
 
     const int spp = tid / TPT, sc0 = (tid % TPT) * CPT;
@@ -476,18 +483,19 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_g_kernel(const ScanArgs a)
     auto load_regs = [&](int q) {
         const int p = q * TB + spp;
         const bool valid = p < ntok;
-        const int t = a.reverse ? ntok - 1 - p : p;
-        const long idx = base + (long)t * a.C + sc0;
+        [[maybe_unused]] const long idx_r = base + (long)tokmap(p, REV_R) * a.C + sc0, idx_k = base + (long)tokmap(p, REV_K) * a.C + sc0;
+        [[maybe_unused]] const long idx_v = base + (long)tokmap(p, REV_V) * a.C + sc0, idx_w = base + (long)tokmap(p, REV_W) * a.C + sc0;
+        [[maybe_unused]] const long idx_y = base + (long)tokmap(p, REV_Y) * a.C + sc0, idx_p = base + (long)p * a.C + sc0;   // idx_p: scratch indexed by scan position
 #pragma unroll
         for (int c = 0; c < CPT; ++c) { pr[c] = 0.f; pk[c] = 0.f; pv[c] = 0.f; pgy[c] = 0.f; pa[c] = 0.f; }
         if (valid) {
-            ion<T, CPT>::load(gr_ + idx, pr);
-            ion<T, CPT>::load(gk_ + idx, pk);
-            ion<T, CPT>::load(gv_ + idx, pv);
-            ion<T, CPT>::load(ggy + idx, pgy);
-            lds_load<CPT>(a.aux + idx, pa);
+            ion<T, CPT>::load(gr_ + idx_r, pr);
+            ion<T, CPT>::load(gk_ + idx_k, pk);
+            ion<T, CPT>::load(gv_ + idx_v, pv);
+            ion<T, CPT>::load(ggy + idx_y, pgy);
+            lds_load<CPT>(a.aux + idx_p, pa);
         }
-        load_ew<T, CPT>(a, idx, valid, pew);
+        load_ew<T, CPT>(a, idx_w, valid, pew);
     };
     auto write_lds = [&](int buf) {
         float* const ib_ = inb + buf * 5 * TB * ROW + spp * ROW + sc0;
@@ -595,8 +603,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_g_kernel(const ScanArgs a)
         {
             const int p = q * TB + spp;
             const bool valid = p < ntok;
-            const int t = a.reverse ? ntok - 1 - p : p;
-            const long idx = base + (long)t * a.C + sc0;
+            [[maybe_unused]] const long idx_r = base + (long)tokmap(p, REV_R) * a.C + sc0, idx_k = base + (long)tokmap(p, REV_K) * a.C + sc0;
+            [[maybe_unused]] const long idx_v = base + (long)tokmap(p, REV_V) * a.C + sc0, idx_w = base + (long)tokmap(p, REV_W) * a.C + sc0;
+            [[maybe_unused]] const long idx_y = base + (long)tokmap(p, REV_Y) * a.C + sc0, idx_p = base + (long)p * a.C + sc0;   // idx_p: scratch indexed by scan position
             float dk[CPT], gvsum[CPT], dl[CPT];
             lds_load<CPT>(dks + buf * TB * ROW + spp * ROW + sc0, dk);
 #pragma unroll
@@ -619,17 +628,17 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_g_kernel(const ScanArgs a)
                 dew[c] = cew[c];
             }
             lds_store<CPT>(dls + buf * TB * ROW + spp * ROW + sc0, dl);
-            dbuf = buf; dvalid = valid; didx = idx;
+            dbuf = buf; dvalid = valid; didx = idx_w;
             if (valid) {
                 if (a.accumulate) {
                     float o1[CPT], o2[CPT];
-                    ion<T, CPT>::load(ogk + idx, o1);
-                    ion<T, CPT>::load(ogv + idx, o2);
+                    ion<T, CPT>::load(ogk + idx_k, o1);
+                    ion<T, CPT>::load(ogv + idx_v, o2);
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) { ogk_[c] += o1[c]; ogv_[c] += o2[c]; }
                 }
-                ion<T, CPT>::store(ogk + idx, ogk_);
-                ion<T, CPT>::store(ogv + idx, ogv_);
+                ion<T, CPT>::store(ogk + idx_k, ogk_);
+                ion<T, CPT>::store(ogv + idx_v, ogv_);
             }
         }
     }

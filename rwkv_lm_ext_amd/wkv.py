@@ -96,6 +96,42 @@ class WKV_6_REV(torch.autograd.Function):
             return (None, None, None, None, gr, gk, gv, gw, _sum_bf16(gu, (ctx.H, ctx.C // ctx.H)), None, None)
 
 
+class WKV_6_PAIR(torch.autograd.Function):
+    """The two operator calls of a bidirectional time-mix layer as ONE launch per pass (second half):
+    problem 0 = the plain forward-direction call WKV_6.apply(r0, k0, v0, w0, u), problem 1 = the reversed-direction call
+    WKV_6_REV.apply(r1, k1, v1, w1, u, rev_n, rev_mask) -- composition B (src/model_bi.py:331-348): r1 = r0, w1 = w0, k1 = k0,
+    v1 = v0 with rev_mask = K | V | Y; composition C (src/model_ext.py:421-437): the reversed stream's own projections with
+    rev_mask = ALL.  Returns (y0, y1), bit-identical to the two separate calls."""
+
+    @staticmethod
+    def forward(ctx, B, T, C, H, r0, k0, v0, w0, r1, k1, v1, w1, u, rev_n, rev_mask):
+        with torch.no_grad():
+            _assert_inputs(C, H, r0, k0, v0, w0, u)
+            _assert_inputs(C, H, r1, k1, v1, w1, u)
+            ctx.H, ctx.C, ctx.rev_mask = H, C, rev_mask
+            ctx.save_for_backward(r0, k0, v0, w0, r1, k1, v1, w1, u, rev_n)
+            ctx.ckpts = [wkv6_op.new_checkpoint(B, T, C, H, r0.device) if _keep_ckpt(ctx) else None for _ in range(2)]
+            sets = [dict(r=r0, k=k0, v=v0, w=w0, ckpt=ctx.ckpts[0]),
+                    dict(r=r1, k=k1, v=v1, w=w1, ckpt=ctx.ckpts[1], rev_n=rev_n, rev_mask=rev_mask)]
+            return wkv6_op.forward_pair_ex(H, u, sets)
+
+    @staticmethod
+    def backward(ctx, gy0, gy1):
+        with torch.no_grad():
+            r0, k0, v0, w0, r1, k1, v1, w1, u, rev_n = ctx.saved_tensors
+            shape = (ctx.H, ctx.C // ctx.H)
+            if ctx.ckpts[0] is None:                       # RWKV_AMD_NO_CKPT=1: nothing was kept, each backward runs its own state pass
+                g0 = wkv6_op.backward_ex(r0, k0, v0, w0, u, gy0.contiguous(), ctx.H)
+                g1 = wkv6_op.backward_rev_ex(r1, k1, v1, w1, u, gy1.contiguous(), ctx.H, rev_n, ctx.rev_mask)
+                return (None, None, None, None, *g0[:4], *g1[:4], _sum_bf16(g0[4], shape) + _sum_bf16(g1[4], shape), None, None)
+            sets = [dict(r=r0, k=k0, v=v0, w=w0, gy=gy0.contiguous(), ckpt=ctx.ckpts[0]),
+                    dict(r=r1, k=k1, v=v1, w=w1, gy=gy1.contiguous(), ckpt=ctx.ckpts[1], rev_n=rev_n, rev_mask=ctx.rev_mask)]
+            g0, g1 = wkv6_op.backward_pair_ex(ctx.H, u, sets)
+            ctx.ckpts = None
+            gu = _sum_bf16(g0[4], shape) + _sum_bf16(g1[4], shape)     # as autograd adds the two calls' bf16 gu
+            return (None, None, None, None, *g0[:4], *g1[:4], gu, None, None)
+
+
 class WKV_6_GN(torch.autograd.Function):
     """WKV_6 followed by the time-mix block's `ln_x` GroupNorm(H) and gate multiply (src/model.py:462-468) in ONE forward kernel
     (SURVEY.md 8f row n1): out = GroupNorm_H(WKV6(r,k,v,w,u); gamma, beta, eps) * g.  The operator's output y makes no round trip

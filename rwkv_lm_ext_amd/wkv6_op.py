@@ -310,36 +310,97 @@ def _check_rev(B, rev_n, rev_mask, dev):
         raise RuntimeError(f"rev_mask {rev_mask} has unknown bits")
 
 
-def forward_rev_ex(r, k, v, w, u, H, rev_n, rev_mask, y=None, ckpt=None):
+def forward_rev_ex(r, k, v, w, u, H, rev_n, rev_mask, y=None, ckpt=None, algo=None):
     """WKV6 over partially reversed sequences without materialising the reversal (include/wkv6_amd.h, wkv6_forward_rev_ex):
     tokens [0, rev_n[b]) of the tensors named in `rev_mask` (REV_R | REV_K | REV_V | REV_W | REV_Y) are taken in reverse
-    order, the rest in place; bf16 only."""
+    order, the rest in place.  I/O type of `r`: bf16 (chunked MFMA kernels; algo="scan" forces the exact ones) or fp32 (exact
+    scan kernels)."""
     B, T, C = r.shape
-    btc, io = (B, T, C), torch.bfloat16
+    btc, io = (B, T, C), r.dtype
+    if io not in (torch.bfloat16, torch.float32):
+        raise RuntimeError(f"unsupported I/O dtype {io}")
     if y is None:
         y = torch.empty(btc, device=r.device, dtype=io)
     named = dict(r=(r, btc, io), k=(k, btc, io), v=(v, btc, io), w=(w, btc, io), u=(u, (H, HEAD_SIZE), io), y=(y, btc, io))
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     _check_rev(B, rev_n, rev_mask, dev)
+    flags = _lib.W_RAW | (_lib.IO_F32 if io == torch.float32 else 0) | (_lib.ALGO_SCAN if algo == "scan" else 0)
     with torch.cuda.device(dev):
         rc = _lib.load().wkv6_forward_rev_ex(B, T, C, H, _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(y), _ptr(ckpt),
-                                             0 if ckpt is None else ckpt.numel(), _ptr(rev_n), rev_mask, _lib.W_RAW,
+                                             0 if ckpt is None else ckpt.numel(), _ptr(rev_n), rev_mask, flags,
                                              _stream_ptr())
     _lib.check(rc, "wkv6 forward_rev_ex")
     return y
 
 
-def backward_rev_ex(r, k, v, w, u, gy, H, rev_n, rev_mask, ckpt=None):
+def _pair_sets(B, T, C, H, sets, u, bwd):
+    """Check and pack the two problems of a pair launch.  sets: two dicts with r, k, v, w (+ y | gy), ckpt, rev_n, rev_mask."""
+    bf = torch.bfloat16
+    btc = (B, T, C)
+    arr = (_lib.SeqSet * 2)()
+    keep = []                                   # tensors the packed pointers refer to
+    dev = None
+    for i, q in enumerate(sets):
+        named = {n: (q[n], btc, bf) for n in ("r", "k", "v", "w") + (("gy",) if bwd else ("y",))}
+        named["u"] = (u, (H, HEAD_SIZE), bf)
+        dev = _check_tensors(B, T, C, H, named, dtype=bf)
+        rev_n, rev_mask = q.get("rev_n"), q.get("rev_mask", 0)
+        if rev_n is not None:
+            _check_rev(B, rev_n, rev_mask, dev)
+        ckpt = q.get("ckpt")
+        if bwd and ckpt is None:
+            raise RuntimeError("wkv6 pair backward: both problems need the checkpoints their forward wrote")
+        e = arr[i]
+        e.r, e.k, e.v, e.w = _ptr(q["r"]), _ptr(q["k"]), _ptr(q["v"]), _ptr(q["w"])
+        if bwd:
+            outs = [torch.empty(btc, device=dev, dtype=bf) for _ in range(4)] + [torch.empty((B, C), device=dev, dtype=torch.float32)]
+            e.gy, e.gr, e.gk, e.gv, e.gw, e.gu = (_ptr(t) for t in [q["gy"]] + outs)
+            keep.append(outs)
+        else:
+            e.y = _ptr(q["y"])
+        e.ckpt, e.ckpt_bytes = _ptr(ckpt), 0 if ckpt is None else ckpt.numel()
+        e.rev_n, e.rev_mask = _ptr(rev_n), rev_mask if rev_n is not None else 0
+    return arr, keep, dev
+
+
+def forward_pair_ex(H, u, sets):
+    """Both operator calls of a bidirectional time-mix layer in one launch (include/wkv6_amd.h, wkv6_forward_pair_ex; SURVEY.md
+    row n2): `sets` = two dicts {r, k, v, w, [y], [ckpt], [rev_n, rev_mask]} of one shape.  Returns (y0, y1)."""
+    B, T, C = sets[0]["r"].shape
+    for q in sets:
+        if q.get("y") is None:
+            q["y"] = torch.empty((B, T, C), device=q["r"].device, dtype=torch.bfloat16)
+    arr, _, dev = _pair_sets(B, T, C, H, sets, u, bwd=False)
+    with torch.cuda.device(dev):
+        rc = _lib.load().wkv6_forward_pair_ex(B, T, C, H, _ptr(u), arr, _lib.W_RAW, _stream_ptr())
+    _lib.check(rc, "wkv6 forward_pair_ex")
+    return sets[0]["y"], sets[1]["y"]
+
+
+def backward_pair_ex(H, u, sets):
+    """Gradients of forward_pair_ex: two tuples (gr, gk, gv, gw, gu[B,C] fp32), one per problem; `sets` as in the forward plus gy."""
+    B, T, C = sets[0]["r"].shape
+    arr, keep, dev = _pair_sets(B, T, C, H, sets, u, bwd=True)
+    with torch.cuda.device(dev):
+        rc = _lib.load().wkv6_backward_pair_ex(B, T, C, H, _ptr(u), arr, _lib.W_RAW | _lib.PARTIALS_F32, _stream_ptr())
+    _lib.check(rc, "wkv6 backward_pair_ex")
+    return tuple(keep[0]), tuple(keep[1])
+
+
+def backward_rev_ex(r, k, v, w, u, gy, H, rev_n, rev_mask, ckpt=None, algo=None):
     """Gradients of forward_rev_ex: (gr, gk, gv, gw, gu[B,C]); each gradient is laid out like its tensor."""
     B, T, C = r.shape
-    btc, io = (B, T, C), torch.bfloat16
+    btc, io = (B, T, C), r.dtype
+    if io not in (torch.bfloat16, torch.float32):
+        raise RuntimeError(f"unsupported I/O dtype {io}")
     named = dict(r=(r, btc, io), k=(k, btc, io), v=(v, btc, io), w=(w, btc, io), u=(u, (H, HEAD_SIZE), io), gy=(gy, btc, io))
     dev = _check_tensors(B, T, C, H, named, dtype=io)
     _check_rev(B, rev_n, rev_mask, dev)
     gr, gk, gv, gw = (torch.empty(btc, device=dev, dtype=io) for _ in range(4))
     gu = torch.empty((B, C), device=dev, dtype=torch.float32)
-    flags = _lib.W_RAW | _lib.PARTIALS_F32
-    if ckpt is not None:
+    exact = io == torch.float32 or algo == "scan"
+    flags = _lib.W_RAW | _lib.PARTIALS_F32 | (_lib.IO_F32 if io == torch.float32 else 0) | (_lib.ALGO_SCAN if algo == "scan" else 0)
+    if ckpt is not None and not exact:
         ws = ckpt
         flags |= _lib.CKPT_VALID
     else:

@@ -67,6 +67,102 @@ def test_rev_operator_is_the_gather_formulation_bit_for_bit(op, mask_name):
         assert torch.equal(got2, ref), (mask_name, name, "self-contained backward")
 
 
+@pytest.mark.parametrize("io", ["bf16 scan", "fp32"])
+@pytest.mark.parametrize("mask_name", ["K|V|Y", "ALL", "R|W"])
+def test_rev_in_the_exact_scan_kernels(op, io, mask_name):
+    """The same index maps in the token-serial fp32 kernels (fp32 I/O, or bf16 I/O with algo="scan"): bit for bit the gather
+    formulation around the same kernels, forward and every gradient."""
+    B, T, H = 3, 45, 2
+    C = 64 * H
+    bits = dict(R=op.REV_R, K=op.REV_K, V=op.REV_V, W=op.REV_W, Y=op.REV_Y)
+    rev_mask = op.REV_ALL if mask_name == "ALL" else sum(bits[c] for c in mask_name.split("|"))
+    dt = torch.float32 if io == "fp32" else bf
+    algo = None if io == "fp32" else "scan"
+    r, k, v = (rnd(B, T, C, scale=0.5, seed=s).to(dt) for s in (11, 12, 13))
+    w = (rnd(B, T, C, scale=0.7, seed=14).float() - 2.0).to(dt)
+    u = rnd(H, 64, scale=0.3, seed=15).to(dt)
+    gy = rnd(B, T, C, seed=16).to(dt)
+    rev_n = torch.tensor([1, 30, T], dtype=torch.int32, device="cuda")
+    idx = rev_idx_of(rev_n, T)
+    on = {c: bool(rev_mask & b) for c, b in bits.items()}
+    y = op.forward_rev_ex(r, k, v, w, u, H, rev_n, rev_mask, algo=algo)
+    got = op.backward_rev_ex(r, k, v, w, u, gy, H, rev_n, rev_mask, algo=algo)
+    rg, kg, vg, wg = gather(r, idx, on["R"]), gather(k, idx, on["K"]), gather(v, idx, on["V"]), gather(w, idx, on["W"])
+    y_ref = gather(op.forward_ex(rg, kg, vg, wg, u, H, algo=algo), idx, on["Y"])
+    g_ref = op.backward_ex(rg, kg, vg, wg, u, gather(gy, idx, on["Y"]), H, algo=algo)
+    want = [gather(g_ref[0], idx, on["R"]), gather(g_ref[1], idx, on["K"]), gather(g_ref[2], idx, on["V"]),
+            gather(g_ref[3], idx, on["W"]), g_ref[4]]
+    assert y.dtype == dt and torch.equal(y, y_ref)
+    for name, a_, b_ in zip("gr gk gv gw gu".split(), got, want):
+        assert torch.equal(a_, b_), (io, mask_name, name)
+
+
+@pytest.mark.parametrize("mask_name", ["K|V|Y", "ALL"])
+@pytest.mark.parametrize("B,T,H", [(4, 150, 2), (10, 96, 32)])          # the second: more slots than CUs, 2 B H = 640 workgroups
+def test_pair_launch_is_the_two_calls_bit_for_bit(op, mask_name, B, T, H):
+    """wkv6_forward_pair_ex / wkv6_backward_pair_ex (row n2, second half): the forward-direction and the reversed-direction
+    operator call of a bidirectional layer in one launch = the two separate calls, bit for bit."""
+    C = 64 * H
+    rev_mask = op.REV_ALL if mask_name == "ALL" else op.REV_K | op.REV_V | op.REV_Y
+    mk = lambda s0: [rnd(B, T, C, scale=0.5, seed=s0 + i) for i in range(3)] + [(rnd(B, T, C, scale=0.7, seed=s0 + 3).float() - 2.0).to(bf)]
+    p0 = mk(20)
+    p1 = mk(30) if mask_name == "ALL" else p0                  # composition B feeds the same tensors to both directions
+    u = rnd(H, 64, scale=0.3, seed=5)
+    gy0, gy1 = rnd(B, T, C, seed=6), rnd(B, T, C, seed=7)
+    rev_n = torch.randint(0, T + 1, (B,), generator=torch.Generator().manual_seed(1)).to(torch.int32).cuda()
+    rev_n[0], rev_n[-1] = 0, T
+    ck = [op.new_checkpoint(B, T, C, H, u.device) for _ in range(4)]
+    y0 = op.forward_ex(*p0, u, H, ckpt=ck[0])
+    y1 = op.forward_rev_ex(*p1, u, H, rev_n, rev_mask, ckpt=ck[1])
+    g0 = op.backward_ex(*p0, u, gy0, H, ckpt=ck[0])
+    g1 = op.backward_rev_ex(*p1, u, gy1, H, rev_n, rev_mask, ckpt=ck[1])
+    names = ("r", "k", "v", "w")
+    sets = [dict(zip(names, p0), ckpt=ck[2]), dict(zip(names, p1), ckpt=ck[3], rev_n=rev_n, rev_mask=rev_mask)]
+    py0, py1 = op.forward_pair_ex(H, u, sets)
+    assert torch.equal(py0, y0) and torch.equal(py1, y1)
+    assert torch.equal(ck[2], ck[0]) and torch.equal(ck[3], ck[1])
+    sets[0]["gy"], sets[1]["gy"] = gy0, gy1
+    pg0, pg1 = op.backward_pair_ex(H, u, sets)
+    for name, a_, b_ in zip("gr gk gv gw gu".split(), pg0, g0):
+        assert torch.equal(a_, b_), ("forward direction", name)
+    for name, a_, b_ in zip("gr gk gv gw gu".split(), pg1, g1):
+        assert torch.equal(a_, b_), ("reversed direction", name)
+    # a forward nobody differentiates needs no checkpoints; the backward does
+    sets2 = [dict(zip(names, p0)), dict(zip(names, p1), rev_n=rev_n, rev_mask=rev_mask)]
+    qy0, qy1 = op.forward_pair_ex(H, u, sets2)
+    assert torch.equal(qy0, y0) and torch.equal(qy1, y1)
+    sets2[0]["gy"], sets2[1]["gy"] = gy0, gy1
+    with pytest.raises(RuntimeError):
+        op.backward_pair_ex(H, u, sets2)
+
+
+@pytest.mark.parametrize("comp", ["B", "C"])
+def test_compositions_with_pair_launch_equal_two_launches(comp):
+    """Tmix_x060.forward_bi_b / forward_bi_c with pair_launch on and off: same outputs and parameter gradients, bit for bit."""
+    torch.manual_seed(0)
+    n_embd, H = 128, 2
+    B, T = 3, 70
+    layer = callers.Tmix_x060(n_embd, n_embd).cuda().to(bf)
+    for p_ in layer.parameters():
+        torch.nn.init.normal_(p_, std=0.05)
+    x = rnd(B, T, n_embd, seed=3)
+    mask = torch.ones(B, T, device="cuda")
+    mask[1, 40:] = 0
+    mask[2, 1:] = 0
+    rev_idx = callers.reverse_x_idx(mask, T)
+    res = []
+    for pair in (True, False):
+        layer.pair_launch = pair
+        layer.zero_grad()
+        xx = x.clone().requires_grad_(True)
+        out = layer.forward_bi_b(xx, mask) if comp == "B" else layer.forward_bi_c(xx, rev_idx, mask)
+        out.float().square().sum().backward()
+        res.append((out.detach(), xx.grad, [p_.grad.clone() for p_ in layer.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a_, b_ in zip(res[0][2], res[1][2]):
+        assert torch.equal(a_, b_)
+
+
 def test_rev_operator_rejects_bad_arguments(op):
     B, T, H = 2, 64, 1
     C = 64

@@ -53,5 +53,55 @@ def run(tm, comp, n=20):
 
 
 for comp in ("b", "c"):
-    t_in, t_ga = run(module(True), comp), run(module(False), comp)
-    print(f"composition {comp.upper()}: fwd+bwd of one time-mix layer  in-kernel reversal {t_in:.3f} ms   gather formulation {t_ga:.3f} ms", flush=True)
+    for rnd in range(2):
+        tm = module(True)
+        t_pair = run(tm, comp)
+        tm.pair_launch = False
+        t_in = run(tm, comp)
+        t_ga = run(module(False), comp)
+        print(f"composition {comp.upper()}: fwd+bwd of one time-mix layer  pair launch {t_pair:.3f} ms   in-kernel reversal, two launches "
+              f"{t_in:.3f} ms   gather formulation {t_ga:.3f} ms", flush=True)
+
+# the operator calls alone: the two problems of a layer as one launch per pass against two
+from rwkv_lm_ext_amd import wkv6_op as op                         # noqa: E402
+H = C // 64
+mk = lambda: [torch.randn(B, T, C, device=dev, generator=g).mul_(0.5).to(bf) for _ in range(3)] + \
+    [(torch.randn(B, T, C, device=dev, generator=g) * 0.7 - 2.0).to(bf)]
+p0, p1 = mk(), mk()
+u = (torch.randn(H, 64, device=dev, generator=g) * 0.3).to(bf)
+gy0, gy1 = dout, dout.flip(1).contiguous()
+rev_n = lens.to(torch.int32)
+ck = [op.new_checkpoint(B, T, C, H, dev) for _ in range(2)]
+names = ("r", "k", "v", "w")
+
+
+def two():
+    op.forward_ex(*p0, u, H, ckpt=ck[0])
+    op.forward_rev_ex(*p1, u, H, rev_n, op.REV_ALL, ckpt=ck[1])
+    op.backward_ex(*p0, u, gy0, H, ckpt=ck[0])
+    op.backward_rev_ex(*p1, u, gy1, H, rev_n, op.REV_ALL, ckpt=ck[1])
+
+
+def one():
+    sets = [dict(zip(names, p0), ckpt=ck[0]), dict(zip(names, p1), ckpt=ck[1], rev_n=rev_n, rev_mask=op.REV_ALL)]
+    op.forward_pair_ex(H, u, sets)
+    sets[0]["gy"], sets[1]["gy"] = gy0, gy1
+    op.backward_pair_ex(H, u, sets)
+
+
+def timeit(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for rnd in range(3):
+    print(f"operator only, both directions fwd+bwd (B=48, T=512, full length): two launches per pass {timeit(two):.4f} ms   "
+          f"one launch per pass {timeit(one):.4f} ms", flush=True)
