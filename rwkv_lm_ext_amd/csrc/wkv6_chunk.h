@@ -70,6 +70,24 @@ __device__ __forceinline__ f4v mfma32(b8v a, b8v b, f4v c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// Exchanges among the token lanes of a producer wave (lane bits 3..5) on the vector ALU instead of the LDS crossbar
+// (ds_bpermute: ~100+ cycles of latency each on the producers' dependent chain, which is the critical path of a stage):
+// bit 3 = the other half of the DPP row (row_ror:8), bits 4 / 5 = v_permlane16_swap / v_permlane32_swap of two copies of the value,
+// which hand every lane both its own row's (half's) value and its partner's.
+constexpr int DPP_SHL4 = 0x104;      // row_shl:4 (lane i <- lane i + 4)
+__device__ __forceinline__ void rows16(float x, float& even, float& odd)    // even = x of the even row of each row pair, in both rows
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    even = __uint_as_float(r[0]);
+    odd = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void halves32(float x, float& lower, float& upper)   // lower = x of lane & 31, in both halves
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lower = __uint_as_float(r[0]);
+    upper = __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ b8v ld_b8(const char* p) { return *reinterpret_cast<const b8v*>(p); }
 __device__ __forceinline__ b8v ld_b8_2x4(const char* p0, const char* p1)
 {

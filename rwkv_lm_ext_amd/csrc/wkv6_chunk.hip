@@ -155,14 +155,16 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             float pre[4], c8[4], c16[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float inc = cs[3][c];
-                float t = __shfl_up(inc, 16);
-                if (tq >= 1) inc += t;
-                t = __shfl_up(inc, 32);
-                if (tq >= 2) inc += t;
-                pre[c] = inc - cs[3][c];                                 // decay accumulated before this lane's tokens
-                c8[c] = __shfl(pre[c], 32 + c4);                         // ... before token 8
-                c16[c] = __shfl(inc, 48 + c4);                           // whole block
+                // exclusive prefix over the four token quads (= the four DPP rows) by butterfly on the vector ALU
+                // (v_permlane16_swap / v_permlane32_swap, wkv6_chunk.h) instead of four dependent ds_bpermute round trips
+                float a_, b_;
+                rows16(cs[3][c], a_, b_);
+                float pfx = (tq & 1) ? a_ : 0.f;
+                halves32(a_ + b_, a_, b_);
+                pfx += (tq & 2) ? a_ : 0.f;
+                pre[c] = pfx;                                            // decay accumulated before this lane's tokens
+                c8[c] = a_;                                              // ... before token 8 (rows 0, 1)
+                c16[c] = a_ + b_;                                        // whole block
                 dtot[c] += c16[c];                                       // ... and over all the blocks this wave prepares
             }
             if (tq == 0) {

@@ -1,3 +1,6 @@
+// PARKED EXPERIMENT (round 3), not built into the library: the 12-wave backward of csrc/wkv6_chunk_bwd12.hip with the state touched once
+// per 32-token stage instead of once per 16-token block.  Parity-green (all GPU tests) and 7 % fewer VALU instructions, but not faster:
+// profiles/r03_stage_level_backward.txt.  Drop-in for csrc/wkv6_chunk_bwd12.hip (same entry points) to reproduce.
 // Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O): 12-wave staged kernel.  Companion of wkv6_chunk.hip.
 //
 // Per 16-token block (a = query token, b = key token, c_a exclusive cumulative log decay, S = forward state at
@@ -32,7 +35,7 @@ namespace {
 
 using namespace chunk;
 
-enum { B_RH = 0, B_RL, B_KH, B_KL, B_V, B_GY, B_R, B_K, NB_ARR };      // bf16 [16][RSB/2] each
+enum { B_RH = 0, B_RL, B_KH, B_KL, B_V, B_GY, NB_ARR };                // bf16 [16][RSB/2] each
 constexpr int FRS = 72 * 4;                                            // bytes per fp32 token row (conflict-free float4 row reads)
 constexpr int BOFF_FR = NB_ARR * ARR;                                  // float [16][72]  fR_a = e^{c_a - c_8}
 constexpr int BOFF_FK = BOFF_FR + BLK * FRS;                           // float [16][72]  fK_a = e^{c_8 - c_{a+1}}
@@ -44,7 +47,11 @@ constexpr int BOFF_COEF = BOFF_E16M8 + 256;                            // float 
 constexpr int BOFF_VG = BOFF_COEF + 128;                               // float [2][16]  per-half gy_a . v_a
 constexpr int BBLK_BYTES = BOFF_VG + 128;
 constexpr int STG = 32, SBLK = STG / BLK;                             // tokens / blocks per stage
-constexpr int BUF_BYTES = SBLK * BBLK_BYTES;                           // one stage image; two of them
+// per stage, behind the two block images: what block 0 needs to meet block 1 and the stage-exit G (m1 = C at token 24 of the stage)
+constexpr int XOFF_KPH = SBLK * BBLK_BYTES;                            // bf16 [16][RSB/2]  hi of Khat'_b = k_b 2^{m1 - C_{b+1}}, b in block 0
+constexpr int XOFF_KPL = XOFF_KPH + ARR;                               //                   lo
+constexpr int XOFF_FKP = XOFF_KPL + ARR;                               // float [16][72]    fK'_b = 2^{m1 - C_{b+1}}
+constexpr int BUF_BYTES = XOFF_FKP + BLK * FRS;                        // one stage image; two of them
 constexpr int CKQ_OFF = 2 * BUF_BYTES;                                 // float [4 row waves][16][64]: next stage's checkpoint (LDS-DMA)
 constexpr int BWD12_LDS = CKQ_OFF + 4 * 4096;
 
@@ -57,6 +64,24 @@ constexpr int BWD12_LDS = CKQ_OFF + 4 * 4096;
     "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
     "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf" \
     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
+
+// Exchanges among the eight token-pair lanes of a producer wave (lane bits 3..5) on the vector ALU instead of the LDS crossbar
+// (ds_bpermute: ~100+ cycles of latency each on the producers' dependent chain, which is the critical path of a stage):
+// bit 3 = the other half of the DPP row (row_ror:8), bits 4 / 5 = v_permlane16_swap / v_permlane32_swap of two copies of the value,
+// which hand every lane both its own row's (half's) value and its partner's.
+constexpr int DPP_SHL4 = 0x104;      // row_shl:4 (lane i <- lane i + 4)
+__device__ __forceinline__ void rows16(float x, float& even, float& odd)    // even = x of the even row of each row pair, in both rows
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    even = __uint_as_float(r[0]);
+    odd = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void halves32(float x, float& lower, float& upper)   // lower = x of lane & 31, in both halves
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lower = __uint_as_float(r[0]);
+    upper = __uint_as_float(r[1]);
+}
 
 // split a C-layout tile pair (8 floats) into the hi / lo bf16x8 fragments of one k-step
 __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4], b8v& hi, b8v& lo)
@@ -150,8 +175,8 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
     float uu[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + ch0, uu);
 
-    uint2 pr[2], pk[2], pv[2], pg[2], pw[2];
-    float4 pe[2];
+    uint2 pr[2], pk[2], pv[2], pg[2], pw[2], pwn = make_uint2(0u, 0u);
+    float4 pe[2], pen = make_float4(0.f, 0.f, 0.f, 0.f);
     const rsrc_t rs_r = make_rsrc(gr_, nbytes), rs_k = make_rsrc(gk_, nbytes), rs_v = make_rsrc(gv_, nbytes), rs_g = make_rsrc(ggy, nbytes);
     const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, nbytes)
                               : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? (unsigned)(ntok - 1) * a.C * 4u + 256u : 0u);
@@ -168,6 +193,11 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             pg[tt] = buf_load8(rs_g, ig * 2u);
             if constexpr (W_RAW) pw[tt] = buf_load8(rs_w, iw * 2u);
             else pe[tt] = buf_load16f(rs_w, iw * 4u);
+        }
+        if (pb == 0) {   // block-0 waves also need the decay of the first half of block 1 (m1): this lane's share is token 16 + tq
+            const unsigned iw = (unsigned)(tokmap(grp * STG + BLK + tq, REV_W) * a.C + ch0);
+            if constexpr (W_RAW) pwn = buf_load8(rs_w, iw * 2u);
+            else pen = buf_load16f(rs_w, iw * 4u);
         }
     };
 
@@ -204,7 +234,7 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             for (int c = 0; c < 4; ++c) part = fmaf(r[tt][c] * uu[c], k[tt][c], part);
             part += dpp_mov<DPP_XOR1>(part);
             part += dpp_mov<DPP_XOR2>(part);
-            part += dpp_mov<DPP_SHL4>(part);
+            part += dpp_mov<DPP_SHL4>(part);                              // the 8 lanes that share this token: total in lane c8i = 0
             const int tok = 2 * tq + tt;
             char* const row = bb + tok * RSB + ch0 * 2;
             // vg_a = gy_a . v_a, this half's 32 channels (exact bf16 products, fp32 sums): the row waves' diagonal of dA
@@ -220,11 +250,6 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             }
             *reinterpret_cast<uint2*>(row + B_V * ARR) = pv[tt];
             *reinterpret_cast<uint2*>(row + B_GY * ARR) = pg[tt];
-            // raw r, k: only read as (token x, 4 channels) uint2 by the row waves; tokens >= 8 keep their 16-byte units swapped
-            // in pairs so that rows x and x + 8 (same bank at the 160-B stride) do not collide in that read
-            char* const rowz = bb + tok * RSB + ((ch0 * 2) ^ ((tok & 8) << 1));
-            *reinterpret_cast<uint2*>(rowz + B_R * ARR) = pr[tt];
-            *reinterpret_cast<uint2*>(rowz + B_K * ARR) = pk[tt];
             *reinterpret_cast<float4*>(bb + BOFF_LW + tok * FRS + ch0 * 4) = make_float4(lwe[0], lwe[1], lwe[2], lwe[3]);
         }
         float pre[4], c8[4], c16[4];
@@ -275,6 +300,43 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             *reinterpret_cast<float4*>(bb + BOFF_FR + tok * FRS + ch0 * 4) = make_float4(fr[0], fr[1], fr[2], fr[3]);
             *reinterpret_cast<float4*>(bb + BOFF_FK + tok * FRS + ch0 * 4) = make_float4(fk[0], fk[1], fk[2], fk[3]);
         }
+        if (pb == 0) {
+            // Block 0 in the frame of block 1's reference point m1 = c16 + (sum of the first 8 decays of block 1): Khat'_b and fK'_b
+            // carry the keys of block 0 to the queries of block 1 and to the stage-exit G.  All exponents are <= 0: a factor that
+            // underflows scales a term that is negligible at any gradient scale.
+            const bool validn = grp * STG + BLK + tq < ntok;
+            float lwn[4], m1[4];
+            if constexpr (W_RAW) {
+                lwn[0] = -exp2_fast(LOG2E * bf_lo(pwn.x)); lwn[1] = -exp2_fast(LOG2E * bf_hi(pwn.x));
+                lwn[2] = -exp2_fast(LOG2E * bf_lo(pwn.y)); lwn[3] = -exp2_fast(LOG2E * bf_hi(pwn.y));
+            } else {
+                lwn[0] = pen.x; lwn[1] = pen.y; lwn[2] = pen.z; lwn[3] = pen.w;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = validn ? fmaxf(lwn[c] * LOG2E, LW_MIN2) : 0.f, a_, b_;
+                t += dpp_mov<DPP_ROR8>(t);
+                rows16(t, a_, b_);
+                halves32(a_ + b_, a_, b_);
+                m1[c] = c16[c] + (a_ + b_);
+            }
+            char* const xb = smem + (grp & 1) * BUF_BYTES;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                float kp[4], fkp[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    fkp[c] = exp2_fast(m1[c] - (pre[c] + cs[tt][c]));
+                    kp[c] = k[tt][c] * fkp[c];
+                }
+                const int tok = 2 * tq + tt;
+                uint2 hi, lo;
+                split4(kp, hi, lo);
+                *reinterpret_cast<uint2*>(xb + XOFF_KPH + tok * RSB + ch0 * 2) = hi;
+                *reinterpret_cast<uint2*>(xb + XOFF_KPL + tok * RSB + ch0 * 2) = lo;
+                *reinterpret_cast<float4*>(xb + XOFF_FKP + tok * FRS + ch0 * 4) = make_float4(fkp[0], fkp[1], fkp[2], fkp[3]);
+            }
+        }
     };
 
     // ---- phase-C role
@@ -313,11 +375,11 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
     } else
     if (rowrole) {
         // =============== key rows [16wv, 16wv+16): gr, gk, gw, gu ==========================================
-        // ST[blk][jt][q] = S_entry(blk)[i = 16wv + x][j = tile_ch(jt) + 8g + q]   (transposed tiles: lane = key row)
-        // GI[jt][q]      = G[i = 16wv + x][j = tile_ch(jt) + 8g + q]
+        // ST[jt][q] = S_entry(stage)[i = 16wv + x][j = tile_ch(jt) + 8g + q]   (transposed tiles: lane = key row)
+        // GI[jt][q] = G[i = 16wv + x][j = tile_ch(jt) + 8g + q]
         float ue[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
-        f4v ST[SBLK][4], GI[4];
+        f4v ST[4], GI[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) GI[t] = f4v{0.f, 0.f, 0.f, 0.f};
         float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -378,45 +440,40 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
 #pragma unroll
                 for (int q = 0; q < 4; ++q)   // dword x&3 of the float4 fetched for column q
                     t4[q] = *reinterpret_cast<const float*>(qreg + jt * 1024 + q * 128 + qrd);
-                ST[0][jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
+                ST[jt] = f4v{t4[0], t4[1], t4[2], t4[3]};
             }
 #ifdef WKV6_STAMP
-            asm volatile("" :: "v"(ST[0][0][0]), "v"(ST[0][1][0]), "v"(ST[0][2][0]), "v"(ST[0][3][0]), "v"(ST[0][0][3]), "v"(ST[0][3][3]));
+            asm volatile("" :: "v"(ST[0][0]), "v"(ST[1][0]), "v"(ST[2][0]), "v"(ST[3][0]), "v"(ST[0][3]), "v"(ST[3][3]));
 #endif
             WKV6_T(ts1);
             const char* const buf = smem + (grp & 1) * BUF_BYTES;
-
-            // ---- rebuild the entry state of block 1:  S <- E16 (.) S + E16m8 (.) (Khat^T V)
+            // The state is touched ONCE per stage: S (stage entry) serves both blocks as it stands -- block 1 sees it through the
+            // output-row factor 2^{m1} = E16(0) E8(1) and meets the keys of block 0 through the cross tile dA10 . Khat' -- so there
+            // is no rebuild of a second block state and one hi/lo split instead of two.  k-slot (s, g, e) <-> value channel 32s + 8g + e.
+            b8v Shi[2], Slo[2];
 #pragma unroll
-            for (int blk = 0; blk < SBLK - 1; ++blk) {
-                {
-                    const char* const bb = buf + blk * BBLK_BYTES;
-                    const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
-                    const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
-                    const float e16 = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
-                    const float e16m8 = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
+            for (int s = 0; s < 2; ++s) {
+                float t0[4], t1[4];
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
-                        const s4v vf = tr_read(bb + B_V * ARR + trow + tile_tr(jt));     // V[4g+e][tile_ch(jt) + 8(x>>2) + (x&3)]
-                        f4v o = {0.f, 0.f, 0.f, 0.f};
-                        o = mfma16(vf, khf, o);
-                        o = mfma16(vf, klf, o);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) ST[blk + 1][jt][q] = fmaf(e16, ST[blk][jt][q], e16m8 * o[q]);
-                    }
-                }
+                for (int q = 0; q < 4; ++q) { t0[q] = ST[2 * s][q]; t1[q] = ST[2 * s + 1][q]; }
+                split8(t0, t1, Shi[s], Slo[s]);
             }
-
-            // Request the next stage's checkpoint.  The read-back above must have delivered before the region is overwritten:
-            // by now (the rebuild consumed the values) it has, the wait only states it; placed here rather than right after
-            // the read-back so that the LDS latency of the read-back runs under the rebuild's operand reads and MFMAs.
+            // Request the next stage's checkpoint: the read-back above has delivered (the split consumed it), the wait only states it.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (grp > 0) request_ckpt(grp - 1);
+            // raw r, k of this wave's (token, channel) quads for the epilogues: straight from global memory (L2: the producers
+            // fetched the same lines one stage ago), not through the LDS image
+            uint2 rr[SBLK], kk[SBLK];
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                const int p = grp * STG + blk * BLK + x, ch = 16 * wv + 4 * g;
+                rr[blk] = buf_load8(rs_r, (unsigned)(tokmap(p, REV_R) * a.C + ch) * 2u);
+                kk[blk] = buf_load8(rs_k, (unsigned)(tokmap(p, REV_K) * a.C + ch) * 2u);
+            }
             WKV6_T(ts2);
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
-            //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
-            //      Four independent blocks => many instructions in flight.
-            f4v ackp[SBLK];
+            //      dA (both diagonal tiles and the cross tile), the whole gr path and the Rhat.dA parts of gk.
+            f4v ackp[SBLK], ak10 = {0.f, 0.f, 0.f, 0.f};         // ak10: sum_{a in block 1} Rhat_a[i] dA[a][b], b in block 0
             float at[SBLK][4], vgs[SBLK];
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
@@ -424,17 +481,20 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 float old_gr[4] = {0.f, 0.f, 0.f, 0.f};
                 fetch_old(0, ogr, grp * STG + blk * BLK + x, REV_R, 16 * wv + 4 * g, old_gr);
                 f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
-                b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: also the B operand of accr
+                f4v dX_ab = {0.f, 0.f, 0.f, 0.f}, dX_ba = {0.f, 0.f, 0.f, 0.f};   // block 1 only: queries of block 1 x keys of block 0
+                b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: also the B operand of accs
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int off = x * RSB + (32 * s + 8 * g) * 2;
                     gyr[s] = ld_b8(bb + B_GY * ARR + off);
-#ifdef WKV6_ABL_DA                                               // timing-only ablation: three of the four row waves skip dA
-                    if (wv != 0) continue;
-#endif
                     const b8v vr = ld_b8(bb + B_V * ARR + off);
                     dA_ab = mfma32(gyr[s], vr, dA_ab);           // [row a][col b]: lane col b = x, rows a = 4g+q
                     dA_ba = mfma32(vr, gyr[s], dA_ba);           // [row b][col a]: lane col a = x, rows b = 4g+q
+                    if (blk == 1) {
+                        const b8v v0 = ld_b8(buf + B_V * ARR + off);
+                        dX_ab = mfma32(gyr[s], v0, dX_ab);       // dA[a in 1][b in 0]
+                        dX_ba = mfma32(v0, gyr[s], dX_ba);
+                    }
                 }
                 // vg_x = dA[x][x] = gy_x . v_x: the producers' two half sums
                 const float vg = *reinterpret_cast<const float*>(bb + BOFF_VG + x * 4) + *reinterpret_cast<const float*>(bb + BOFF_VG + 64 + x * 4);
@@ -455,26 +515,39 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
                 const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
                 const s4v klf = tr_read(bb + B_KL * ARR + troff + 32 * wv);
-                // gr accumulator [i_local = 4g+q][token x].  E8 scales key rows = output rows here, so it is applied to the 4
-                // results instead of the 16 operand values (the state tiles are dead after this: split in place, no copy)
-                const float4 e8o = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (16 * wv + 4 * g) * 4);
+                // gr accumulator [i_local = 4g+q][token x]: the state term's decay factor scales key rows = output rows, so it
+                // is applied to the 4 results, not to the operand
                 f4v accs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    float t0[4], t1[4];
-                    b8v hi, lo;                                  // k-slot (s, g, e) <-> value channel 32s + 8g + e
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q]; t1[q] = ST[blk][2 * s + 1][q]; }
-                    split8(t0, t1, hi, lo);
-                    accs = mfma32(hi, gyr[s], accs);
-                    accs = mfma32(lo, gyr[s], accs);
+                    accs = mfma32(Shi[s], gyr[s], accs);
+                    accs = mfma32(Slo[s], gyr[s], accs);
                 }
                 f4v accr16 = {0.f, 0.f, 0.f, 0.f};               // separate accumulator per MFMA shape (see wkv6_chunk.hip)
                 accr16 = mfma16(khf, dba_hi, accr16);            // sum_b Khat[b][i] dA[a][b]
                 accr16 = mfma16(khf, dba_lo, accr16);
                 accr16 = mfma16(klf, dba_hi, accr16);
-                const f4v accr = {fmaf(e8o.x, accs[0], accr16[0]), fmaf(e8o.y, accs[1], accr16[1]),
-                                  fmaf(e8o.z, accs[2], accr16[2]), fmaf(e8o.w, accs[3], accr16[3])};
+                float4 ef = *reinterpret_cast<const float4*>(buf + BOFF_E8 + (16 * wv + 4 * g) * 4);           // block 0: E8
+                if (blk == 1) {
+                    float xab[4] = {dX_ab[0], dX_ab[1], dX_ab[2], dX_ab[3]}, xba[4] = {dX_ba[0], dX_ba[1], dX_ba[2], dX_ba[3]};
+                    split4(xab, th, tl);
+                    const s4v xab_hi = __builtin_bit_cast(s4v, th), xab_lo = __builtin_bit_cast(s4v, tl);
+                    split4(xba, th, tl);
+                    const s4v xba_hi = __builtin_bit_cast(s4v, th), xba_lo = __builtin_bit_cast(s4v, tl);
+                    const s4v kphf = tr_read(buf + XOFF_KPH + troff + 32 * wv);    // Khat'[b = 4g+e of block 0][16wv + x]
+                    const s4v kplf = tr_read(buf + XOFF_KPL + troff + 32 * wv);
+                    accr16 = mfma16(kphf, xba_hi, accr16);       // sum_{b in 0} Khat'_b[i] dA[a][b]
+                    accr16 = mfma16(kphf, xba_lo, accr16);
+                    accr16 = mfma16(kplf, xba_hi, accr16);
+                    ak10 = mfma16(rhf_w, xab_hi, ak10);          // sum_{a in 1} Rhat_a[i] dA[a][b]
+                    ak10 = mfma16(rhf_w, xab_lo, ak10);
+                    ak10 = mfma16(rlf_w, xab_hi, ak10);
+                    const float4 e16a = *reinterpret_cast<const float4*>(buf + BOFF_E16 + (16 * wv + 4 * g) * 4);              // block 0
+                    const float4 e8b = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (16 * wv + 4 * g) * 4);                 // block 1
+                    ef = make_float4(e16a.x * e8b.x, e16a.y * e8b.y, e16a.z * e8b.z, e16a.w * e8b.w);      // 2^{m1}
+                }
+                const f4v accr = {fmaf(ef.x, accs[0], accr16[0]), fmaf(ef.y, accs[1], accr16[1]),
+                                  fmaf(ef.z, accs[2], accr16[2]), fmaf(ef.w, accs[3], accr16[3])};
                 f4v ak = {0.f, 0.f, 0.f, 0.f};
                 ak = mfma16(rhf_w, dab_hi, ak);                  // sum_a Rhat[a][i] dA[a][b]
                 ak = mfma16(rhf_w, dab_lo, ak);
@@ -483,11 +556,9 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 {   // gr, a_t, gu: lane = token x, channels ch .. ch+3
                     const int ch = 16 * wv + 4 * g;
                     const float4 fr4 = *reinterpret_cast<const float4*>(bb + BOFF_FR + x * FRS + ch * 4);
-                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
-                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
                     const float frv[4] = {fr4.x, fr4.y, fr4.z, fr4.w};
-                    const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
-                    const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
+                    const float rv[4] = {bf_lo(rr[blk].x), bf_hi(rr[blk].x), bf_lo(rr[blk].y), bf_hi(rr[blk].y)};
+                    const float kv[4] = {bf_lo(kk[blk].x), bf_hi(kk[blk].x), bf_lo(kk[blk].y), bf_hi(kk[blk].y)};
                     float o_gr[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -501,57 +572,79 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 }
             }
             WKV6_T(ts3);
-            // ---- chain: only the work that needs G
+            // ---- chain: only the work that needs G.  G (stage exit) serves both blocks as it stands: one hi/lo split; block 1 sees it
+            //      through the output-row factor E16m8(1), block 0 through fK' E16m8(1); its update happens once per stage:
+            //      G <- E16(0) E16(1) G + E8(0) (Rhat_0^T gy_0) + E16(0) E8(1) (Rhat_1^T gy_1)
+            b8v Ghi[2], Glo[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float t0[4], t1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q]; t1[q] = GI[2 * s + 1][q]; }
+                split8(t0, t1, Ghi[s], Glo[s]);
+            }
+            {
+                const char* const b1 = buf + BBLK_BYTES;
+                const float e16a = *reinterpret_cast<const float*>(buf + BOFF_E16 + (16 * wv + x) * 4);
+                const float e16b = *reinterpret_cast<const float*>(b1 + BOFF_E16 + (16 * wv + x) * 4);
+                const float e32x = e16a * e16b;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) GI[jt][q] *= e32x;
+            }
+            const float4 em8 = *reinterpret_cast<const float4*>(buf + BBLK_BYTES + BOFF_E16M8 + (16 * wv + 4 * g) * 4);   // E16m8 of block 1, rows 4g+q
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const bb = buf + blk * BBLK_BYTES;
-                const float e8x = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
-                const float e16x = *reinterpret_cast<const float*>(bb + BOFF_E16 + (16 * wv + x) * 4);
-                const float e16m8x = *reinterpret_cast<const float*>(bb + BOFF_E16M8 + (16 * wv + x) * 4);
                 float old_gk[4] = {0.f, 0.f, 0.f, 0.f}, old_gw[4] = {0.f, 0.f, 0.f, 0.f};
                 fetch_old(1, ogk, grp * STG + blk * BLK + x, REV_K, 16 * wv + 4 * g, old_gk);
                 fetch_old(3, ogw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw);
-                // (gy^T Rhat) tiles of the G update: independent of G, issued first so they run under the chain's latency
-                f4v Oi[4];
-                {
+                f4v gvb = {0.f, 0.f, 0.f, 0.f};                  // sum_j G[i][j] v_b[j]
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const b8v vr = ld_b8(bb + B_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
+                    gvb = mfma32(Ghi[s], vr, gvb);
+                    gvb = mfma32(Glo[s], vr, gvb);
+                }
+                {   // (gy^T Rhat) tiles of the G update, scaled into place right away: [row j_local][col i_local = x]
                     const s4v rhf_w = tr_read(bb + B_RH * ARR + troff + 32 * wv);  // Rhat[4g+e][16wv + x]
                     const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
+                    float cx = *reinterpret_cast<const float*>(bb + BOFF_E8 + (16 * wv + x) * 4);
+                    if (blk == 1) cx *= *reinterpret_cast<const float*>(buf + BOFF_E16 + (16 * wv + x) * 4);
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {             // [row j_local][col i_local = x]
+                    for (int jt = 0; jt < 4; ++jt) {
                         const s4v gyf = tr_read(bb + B_GY * ARR + trow + tile_tr(jt));
                         f4v o = {0.f, 0.f, 0.f, 0.f};
                         o = mfma16(gyf, rhf_w, o);
                         o = mfma16(gyf, rlf_w, o);
-                        Oi[jt] = o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(cx, o[q], GI[jt][q]);
                     }
                 }
-                f4v acck = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const b8v vr = ld_b8(bb + B_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
-                    float t0[4], t1[4];
-                    b8v hi, lo;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
-                    split8(t0, t1, hi, lo);
-                    acck = mfma32(hi, vr, acck);
-                    acck = mfma32(lo, vr, acck);
-                }
-                acck += ackp[blk];
                 {
                     const int ch = 16 * wv + 4 * g;
                     const float4 fk4 = *reinterpret_cast<const float4*>(bb + BOFF_FK + x * FRS + ch * 4);
                     const float4 lw4 = *reinterpret_cast<const float4*>(bb + BOFF_LW + x * FRS + ch * 4);
-                    const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
-                    const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
                     const float fkv[4] = {fk4.x, fk4.y, fk4.z, fk4.w}, lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
-                    const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
-                    const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
+                    const float em[4] = {em8.x, em8.y, em8.z, em8.w};
+                    const float rv[4] = {bf_lo(rr[blk].x), bf_hi(rr[blk].x), bf_lo(rr[blk].y), bf_hi(rr[blk].y)};
+                    const float kv[4] = {bf_lo(kk[blk].x), bf_hi(kk[blk].x), bf_lo(kk[blk].y), bf_hi(kk[blk].y)};
+                    float dkv[4];
+                    if (blk == 1) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dkv[q] = fkv[q] * fmaf(em[q], gvb[q], ackp[1][q]);
+                    } else {
+                        const float4 fp4 = *reinterpret_cast<const float4*>(buf + XOFF_FKP + x * FRS + ch * 4);
+                        const float fpv[4] = {fp4.x, fp4.y, fp4.z, fp4.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dkv[q] = fmaf(fpv[q], fmaf(em[q], gvb[q], ak10[q]), fkv[q] * ackp[0][q]);
+                    }
                     const float vg = vgs[blk];
                     float o_gk[4], o_gw[4], bt[4], dl[4], sfx[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float dk = fkv[q] * acck[q];
+                        const float dk = dkv[q];
                         o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
                         bt[q] = kv[q] * dk;
                         dl[q] = at[blk][q] - bt[q];
@@ -571,11 +664,6 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                     emit(1, rs_gk, ogk, p, REV_K, ch, o_gk, old_gk);
                     emit(3, rs_gw, ogw, p, REV_W, ch, o_gw, old_gw);
                 }
-                // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * Oi[jt][q]);
             }
             WKV6_T(ts4);
             __syncthreads();
@@ -605,27 +693,31 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
 #endif
             WKV6_T(ts0);
             const char* const buf = smem + (grp & 1) * BUF_BYTES;
-            // ---- pre-phase: everything that does not depend on G, stage-major over the 4 blocks so that many
-            //      independent LDS reads / MFMAs are in flight (blocks past the end of the sequence are neutral)
-            s4v gyT_w[SBLK], sc_hi[SBLK], sc_lo[SBLK];
+            // ---- pre-phase: everything that does not depend on G, stage-major over the blocks so that many independent LDS
+            //      reads / MFMAs are in flight (blocks past the end of the sequence are neutral).  Three score tiles per stage: the
+            //      two diagonal ones and A10 = Rhat_1 Khat'_0^T (queries of block 1 x keys of block 0, no mask).
+            s4v gyT_w[SBLK], sc_hi[SBLK], sc_lo[SBLK], scx_hi, scx_lo;
             f4v accp[SBLK], Og[SBLK][4];
             {
-                f4v sc[SBLK];
+                f4v sc[SBLK], scx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int blk = 0; blk < SBLK; ++blk) {
                     const char* const bb = buf + blk * BBLK_BYTES;
                     sc[blk] = f4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-#ifdef WKV6_ABL_SC                                               // timing-only ablation: three of the four column waves skip the scores
-                        if (wv != 0) continue;
-#endif
                         const int off = x * RSB + (32 * s + 8 * g) * 2;
                         const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
                         const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
                         sc[blk] = mfma32(rh, kh, sc[blk]);        // A[row a][col b]: lane col b = x, rows a = 4g+q
                         sc[blk] = mfma32(rh, kl, sc[blk]);
                         sc[blk] = mfma32(rl, kh, sc[blk]);
+                        if (blk == 1) {
+                            const b8v ph = ld_b8(buf + XOFF_KPH + off), pl = ld_b8(buf + XOFF_KPL + off);
+                            scx = mfma32(rh, ph, scx);            // A[a in 1][b in 0]
+                            scx = mfma32(rh, pl, scx);
+                            scx = mfma32(rl, ph, scx);
+                        }
                     }
                     gyT_w[blk] = tr_read(bb + B_GY * ARR + troff + 32 * wv);      // gy[4g+e][16wv + x]
                 }
@@ -646,12 +738,23 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                     sc_hi[blk] = __builtin_bit_cast(s4v, th);
                     sc_lo[blk] = __builtin_bit_cast(s4v, tl);
                 }
+                {
+                    const float sx[4] = {scx[0], scx[1], scx[2], scx[3]};
+                    uint2 th, tl;
+                    split4(sx, th, tl);
+                    scx_hi = __builtin_bit_cast(s4v, th);
+                    scx_lo = __builtin_bit_cast(s4v, tl);
+                }
 #pragma unroll
                 for (int blk = 0; blk < SBLK; ++blk) {
                     const char* const bb = buf + blk * BBLK_BYTES;
                     f4v acc = {0.f, 0.f, 0.f, 0.f};               // gv^T[j][b], first part: sum_a gy[a][j] A[a][b]
                     acc = mfma16(gyT_w[blk], sc_hi[blk], acc);
                     acc = mfma16(gyT_w[blk], sc_lo[blk], acc);
+                    if (blk == 0) {                               // the queries of block 1
+                        acc = mfma16(gyT_w[1], scx_hi, acc);
+                        acc = mfma16(gyT_w[1], scx_lo, acc);
+                    }
                     accp[blk] = acc;
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {              // (Rhat^T gy) tile: [row i_local][col j_local = x]
@@ -665,7 +768,22 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 }
             }
             WKV6_T(ts1);
-            // ---- chain: only the work that needs G
+            // ---- chain: only the work that needs G.  One scaled hi/lo operand for the stage: E16m8(1) (.) G meets Khat of block 1 and
+            //      Khat' of block 0 (k_b 2^{C_32 - C_{b+1}} = Khat'_b E16m8(1)).
+            b8v gh[2], gl[2];
+            {
+                const char* const b1 = buf + BBLK_BYTES;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float t0[4], t1[4];
+                    const float4 m0 = *reinterpret_cast<const float4*>(b1 + BOFF_E16M8 + (32 * s + 8 * g) * 4);
+                    const float4 m1 = *reinterpret_cast<const float4*>(b1 + BOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
+                    t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
+                    t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
+                    t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
+                    split8(t0, t1, gh[s], gl[s]);
+                }
+            }
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const bb = buf + blk * BBLK_BYTES;
@@ -675,18 +793,11 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int off = x * RSB + (32 * s + 8 * g) * 2;
-                    const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
-                    float t0[4], t1[4];
-                    const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g) * 4);
-                    const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
-                    t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
-                    t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
-                    t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
-                    b8v gh, gl;
-                    split8(t0, t1, gh, gl);
-                    acc = mfma32(gh, kh, acc);                   // k-slot (s, g, e) <-> key channel 32s + 8g + e
-                    acc = mfma32(gh, kl, acc);
-                    acc = mfma32(gl, kh, acc);
+                    const b8v kh = blk == 1 ? ld_b8(bb + B_KH * ARR + off) : ld_b8(buf + XOFF_KPH + off);
+                    const b8v kl = blk == 1 ? ld_b8(bb + B_KL * ARR + off) : ld_b8(buf + XOFF_KPL + off);
+                    acc = mfma32(gh[s], kh, acc);                // k-slot (s, g, e) <-> key channel 32s + 8g + e
+                    acc = mfma32(gh[s], kl, acc);
+                    acc = mfma32(gl[s], kh, acc);
                 }
                 acc += accp[blk];
                 {
@@ -694,15 +805,19 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                     float o[4] = {acc[0], acc[1], acc[2], acc[3]};
                     emit(2, rs_gv, ogv, p, REV_V, 16 * wv + 4 * g, o, old_gv);
                 }
-                // ---- G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
+            }
+            // ---- G[:][j = 16wv + x] <- E16(0) E16(1) G + E8(0) (Rhat_0^T gy_0) + E16(0) E8(1) (Rhat_1^T gy_1), once per stage
+            {
+                const char* const b1 = buf + BBLK_BYTES;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (tile_ch(it) + 8 * g) * 4);
-                    const float4 d8 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (tile_ch(it) + 8 * g) * 4);
-                    GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * Og[blk][it][0]);
-                    GJ[it][1] = fmaf(d16.y, GJ[it][1], d8.y * Og[blk][it][1]);
-                    GJ[it][2] = fmaf(d16.z, GJ[it][2], d8.z * Og[blk][it][2]);
-                    GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * Og[blk][it][3]);
+                    const int r0 = (tile_ch(it) + 8 * g) * 4;
+                    const float4 a16 = *reinterpret_cast<const float4*>(buf + BOFF_E16 + r0), b16 = *reinterpret_cast<const float4*>(b1 + BOFF_E16 + r0);
+                    const float4 a8 = *reinterpret_cast<const float4*>(buf + BOFF_E8 + r0), b8 = *reinterpret_cast<const float4*>(b1 + BOFF_E8 + r0);
+                    GJ[it][0] = fmaf(a16.x * b16.x, GJ[it][0], fmaf(a16.x * b8.x, Og[1][it][0], a8.x * Og[0][it][0]));
+                    GJ[it][1] = fmaf(a16.y * b16.y, GJ[it][1], fmaf(a16.y * b8.y, Og[1][it][1], a8.y * Og[0][it][1]));
+                    GJ[it][2] = fmaf(a16.z * b16.z, GJ[it][2], fmaf(a16.z * b8.z, Og[1][it][2], a8.z * Og[0][it][2]));
+                    GJ[it][3] = fmaf(a16.w * b16.w, GJ[it][3], fmaf(a16.w * b8.w, Og[1][it][3], a8.w * Og[0][it][3]));
                 }
             }
             WKV6_T(ts2);
