@@ -7,14 +7,25 @@ import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 src, prefix = sys.argv[1], sys.argv[2]
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+def newest(pattern):
+    """gpurun merges a call's output INTO the local gpurun_out/: files of earlier collections may sit beside the new ones -- keep the
+    newest file of every directory."""
+    by_dir = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
+stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
 if stats:      # keep this library's kernels only (the torch kernels of the input generation have kilobyte-long names)
     with open(stats[0]) as fh, open(prefix + "_kernel_stats.csv", "w") as out_fh:
         for i, line in enumerate(fh):
             if i == 0 or "wkv6" in line or "mask_to_lens" in line:
                 out_fh.write(line)
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+for f in newest(os.path.join(src, "pmc*", "**", "*counter_collection.csv")):
     with open(f) as fh:
         per_dispatch = defaultdict(float)
         meta = {}
