@@ -42,6 +42,32 @@ def pmc_from_file():
         return {}
 
 
+def add_counter_rows(rows, acc):
+    """Fold the rows of one rocprofv3 counter_collection.csv into acc[kernel][counter] = [value per dispatch]: a counter of one
+    dispatch may come as several rows (one per dimension instance), which are summed."""
+    per_dispatch = {}
+    for row in rows:
+        kn = row["Kernel_Name"]
+        key = "chunk_bwd12_kernel" if "chunk_bwd12" in kn else "chunk_bwd64_kernel" if "chunk_bwd64" in kn else \
+            "chunk_fwd_kernel" if "chunk_fwd_kernel" in kn else None
+        if key:
+            id_ = (key, row["Counter_Name"], row["Dispatch_Id"])
+            per_dispatch[id_] = per_dispatch.get(id_, 0.0) + float(row["Counter_Value"])
+    for (key, cname, _), val in per_dispatch.items():
+        acc.setdefault(key, {}).setdefault(cname, []).append(val)
+
+
+def reduce_counters(acc):
+    """Per-launch averages and the HBM bytes they imply: FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE counts half of a coalesced
+    stream's bytes on gfx950 (MI355X_MICROARCH.md)."""
+    out = {}
+    for key, d in acc.items():
+        avg = {c: sum(v) / len(v) for c, v in d.items()}
+        if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+            out[key] = {"counters": avg, "hbm_bytes": int(2 * avg["FETCH_SIZE"] * 1024 + avg["WRITE_SIZE"] * 1024)}
+    return out
+
+
 def pmc_live(timeout_s=120):
     """HBM bytes and VALU utilisation of the two kernels, measured NOW: rank 0 at N = 1 runs this same script as a child under
     `rocprofv3 --kernel-trace --pmc <group>` (one run per counter group -- FETCH_SIZE and WRITE_SIZE cannot share a pass -- with a
@@ -68,27 +94,13 @@ def pmc_live(timeout_s=120):
             if r.returncode != 0:
                 return {}
             for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
-                per_dispatch = {}                       # a counter of one dispatch may come as several rows: sum them
                 with open(f) as fh:
-                    for row in csv.DictReader(fh):
-                        kn = row["Kernel_Name"]
-                        key = "chunk_bwd12_kernel" if "chunk_bwd12" in kn else "chunk_bwd64_kernel" if "chunk_bwd64" in kn else \
-                            "chunk_fwd_kernel" if "chunk_fwd_kernel" in kn else None
-                        if key:
-                            id_ = (key, row["Counter_Name"], row["Dispatch_Id"])
-                            per_dispatch[id_] = per_dispatch.get(id_, 0.0) + float(row["Counter_Value"])
-                for (key, cname, _), val in per_dispatch.items():
-                    acc.setdefault(key, {}).setdefault(cname, []).append(val)
+                    add_counter_rows(csv.DictReader(fh), acc)
     except Exception:
         return {}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    res = {}
-    for key, d in acc.items():
-        avg = {c: sum(v) / len(v) for c, v in d.items()}
-        if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
-            res[key] = {"counters": avg, "hbm_bytes": int(2 * avg["FETCH_SIZE"] * 1024 + avg["WRITE_SIZE"] * 1024)}
-    return res
+    return reduce_counters(acc)
 
 
 def pmc_child():

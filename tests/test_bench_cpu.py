@@ -37,3 +37,21 @@ def test_committed_bench_lines_carry_the_contract_fields():
         r = d["roofline"]
         assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
         assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_live_counter_rows_reduce_to_per_launch_hbm_bytes():
+    """bench.pmc_live's parsing: several rows per (dispatch, counter) are summed, launches averaged, FETCH_SIZE doubled (gfx950)."""
+    rows = []
+    kn = "void wkv6::(anonymous namespace)::chunk_bwd12_kernel<true, 0>(wkv6::ScanArgs)"
+    for disp in ("1", "2"):
+        for inst in range(8):                                    # one row per XCD
+            rows.append({"Kernel_Name": kn, "Counter_Name": "FETCH_SIZE", "Dispatch_Id": disp, "Counter_Value": "100.0"})
+            rows.append({"Kernel_Name": kn, "Counter_Name": "WRITE_SIZE", "Dispatch_Id": disp, "Counter_Value": "50.0"})
+    rows.append({"Kernel_Name": "some_torch_kernel", "Counter_Name": "FETCH_SIZE", "Dispatch_Id": "3", "Counter_Value": "9e9"})
+    acc = {}
+    bench.add_counter_rows(rows, acc)
+    out = bench.reduce_counters(acc)
+    assert list(out) == ["chunk_bwd12_kernel"]
+    assert out["chunk_bwd12_kernel"]["counters"] == {"FETCH_SIZE": 800.0, "WRITE_SIZE": 400.0}
+    assert out["chunk_bwd12_kernel"]["hbm_bytes"] == (2 * 800 + 400) * 1024
+
