@@ -174,6 +174,31 @@ def test_python_constants_match_the_header():
     assert _lib.REV_ALL == _lib.REV_R | _lib.REV_K | _lib.REV_V | _lib.REV_W | _lib.REV_Y
 
 
+def test_header_is_plain_c_and_the_pair_struct_matches_ctypes(tmp_path):
+    """include/wkv6_amd.h compiles as C (gcc -std=c99 -pedantic), and wkv6_seq_set has the layout the ctypes mirror assumes."""
+    import subprocess
+    from rwkv_lm_ext_amd import _lib
+    fields = [n for n, _ in _lib.SeqSet._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "wkv6_amd.h"\nint main(void) {\n'
+                   '    printf("%zu\\n", sizeof(wkv6_seq_set));\n'
+                   + "".join(f'    printf("%zu\\n", offsetof(wkv6_seq_set, {n}));\n' for n in fields)
+                   + "    return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(_lib.SeqSet)
+    assert out[1:] == [getattr(_lib.SeqSet, n).offset for n in fields]
+    # no-launch argument checks of the pair entry points
+    lib = _lib.load()
+    sets = (_lib.SeqSet * 2)()
+    assert lib.wkv6_forward_pair_ex(1, 4, 64, 1, None, sets, _lib.W_RAW, None) == -2          # u missing
+    assert lib.wkv6_forward_pair_ex(1, 4, 64, 1, 1, sets, _lib.W_RAW, None) == -2             # tensors missing
+    assert lib.wkv6_forward_pair_ex(1, 4, 64, 1, 1, sets, _lib.W_RAW | _lib.IO_F32, None) == -4
+    assert lib.wkv6_backward_pair_ex(1, 4, 100, 1, 1, sets, _lib.W_RAW, None) == -1
+
+
 def test_oracle_matches_the_medium_reference_fixtures(oracle):
     """T = 160 vectors generated from the reference's CPU recurrence (oracle/gen_golden_medium.py): plain, per-sample state
     (gs, final state), ragged wkv6_bi."""
