@@ -68,7 +68,7 @@ def reduce_counters(acc):
     return out
 
 
-def pmc_live(timeout_s=120):
+def pmc_live(timeout_s=75):
     """HBM bytes and VALU utilisation of the two kernels, measured NOW: rank 0 at N = 1 runs this same script as a child under
     `rocprofv3 --kernel-trace --pmc <group>` (one run per counter group -- FETCH_SIZE and WRITE_SIZE cannot share a pass -- with a
     handful of fwd+bwd launches each) before it touches the GPU itself, and averages the counters per launch.  FETCH_SIZE is
@@ -255,14 +255,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the WKV6 operator has no CPU path")
+    # the profiled child runs come first, while this process has not initialised the GPU (device_count() does not): no fork + exec
+    # from a process that holds a HIP context
     pmc, pmc_source = {}, None
-    if args.workload == "wkv6" and rank == 0 and args.traffic != "none":
+    if args.workload == "wkv6" and rank == 0 and args.traffic != "none" and torch.cuda.device_count() > 0:
         if args.traffic == "live" and world == 1:
             pmc, pmc_source = pmc_live(), "rocprofv3 --pmc child runs of this invocation"
         if not pmc:
             pmc, pmc_source = pmc_from_file(), "profiles/" + os.path.basename(PMC_FILE)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the WKV6 operator has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
