@@ -247,6 +247,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd64_kernel(const ScanArgs a)
         request_ckpt(nC - 1);                                  // (before the loads: phase A infers the DMA's arrival from theirs)
         load_chunk(nC - 1, p, ch0);
         decay_scan(nC - 1, I, p, ch0, x);
+        asm volatile("" : "+v"(pr.x), "+v"(pr.y), "+v"(pk.x), "+v"(pk.y), "+v"(pv.x), "+v"(pv.y), "+v"(pg.x), "+v"(pg.y));   // (see the end of phase C)
     }
     __syncthreads();
     // Lane- and wave-derived quantities (token, channels, LDS addresses, triangle masks, the wave's block / quarter and every
@@ -589,7 +590,14 @@ __global__ __launch_bounds__(1024) void chunk_bwd64_kernel(const ScanArgs a)
                 float o_gv[4] = {ov[0], ov[1], ov[2], ov[3]};
                 emit(2, rs_gv, ogv, pos, REV_V, ch0, o_gv);
             }
-            if (c > 0) decay_scan(c - 1, I, p, ch0, x);
+            if (c > 0) {
+                decay_scan(c - 1, I, p, ch0, x);
+                // The scan has just waited for w, the youngest of the next chunk's input loads, with the exact count of the younger
+                // gradient stores (straight-line code: s_waitcnt vmcnt(3)).  Touch the other four here too: left to the head of the
+                // loop, their wait is placed at a control-flow merge where the compiler's counters have collapsed to vmcnt(0),
+                // which also drains the stores issued just above -- a full store latency exposed at the head of every chunk.
+                asm volatile("" : "+v"(pr.x), "+v"(pr.y), "+v"(pk.x), "+v"(pk.y), "+v"(pv.x), "+v"(pv.y), "+v"(pg.x), "+v"(pg.y));
+            }
         }
         WKV6_T(ts5);
         __syncthreads();
