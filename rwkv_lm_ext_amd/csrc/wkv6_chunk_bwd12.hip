@@ -21,6 +21,8 @@
 //   * "row" waves 0..3 own key rows [16w,16w+16): forward states and G with lane = key row; they produce gr, gk, gw, gu;
 //   * "column" waves 4..7 own value columns [16w,16w+16): G with lane = value column; they produce the scores, gv, gs.
 //     G is kept in both orientations because gk contracts it over j and gv over i;
+//     The tiles all four waves of a role need alike -- dA in both orientations (row waves), the masked scores (column waves) -- are
+//     computed once per workgroup and handed over as MFMA fragments through LDS, each behind a tag its readers poll (XT_OFF below);
 //   * four dedicated producer waves (one per SIMD; wave = block x channel half, lane = 4 channels x 2 tokens) prepare
 //     stage s-1 into the other LDS buffer and issue the global loads of stage s-2 while stage s is consumed
 //     (three waves per SIMD, <= 168 VGPRs).
@@ -46,7 +48,14 @@ constexpr int BBLK_BYTES = BOFF_VG + 128;
 constexpr int STG = 32, SBLK = STG / BLK;                             // tokens / blocks per stage
 constexpr int BUF_BYTES = SBLK * BBLK_BYTES;                           // one stage image; two of them
 constexpr int CKQ_OFF = 2 * BUF_BYTES;                                 // float [4 row waves][16][64]: next stage's checkpoint (LDS-DMA)
-constexpr int BWD12_LDS = CKQ_OFF + 4 * 4096;
+// Tiles that every row wave (dA, both orientations, per block) and every column wave (masked scores per block) needs are computed
+// ONCE per workgroup and handed over as MFMA fragments: row wave w makes dA tile w (block w >> 1, orientation w & 1), column waves 0
+// and 1 make the score tiles of blocks 0 and 1.  The waves of a role are not synchronised inside a stage, so each tile carries a tag
+// (stage index + 1) that its readers poll; the tags live in the unused padding of the first image row.
+constexpr int XT_OFF = CKQ_OFF + 4 * 4096;                             // uint4 [4 tiles][64 lanes]  dA fragments: bf16x4 hi | bf16x4 lo
+constexpr int XS_OFF = XT_OFF + 4 * 1024;                              // uint4 [2 tiles][64 lanes]  score fragments
+constexpr int XFLAG_OFF = 128;                                         // int [6] in the padding of row 0 of the first array of buffer 0
+constexpr int BWD12_LDS = XS_OFF + 2 * 1024;
 
 // One step of four independent in-row suffix sums: x[q] += x[q] of the lane `ctrl` names (lanes without a source keep their
 // value: DPP disables them).  Single v_add_f32_dpp instructions (the builtin gives v_mov_dpp + v_add).  A VALU write of a VGPR
@@ -283,6 +292,27 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
     int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);          // transposed read, tile-labelled columns: + tile_tr(t)
     const int ngrp = (ntok + STG - 1) / STG;                      // stages
     const int nstmax = (a.T + STG - 1) / STG;
+    // (explicit LDS address space: a volatile access through a generic pointer becomes a FLAT instruction whose wait drains the whole
+    // vector-memory queue, checkpoint DMA included)
+    typedef volatile int __attribute__((address_space(3))) lds_vint;
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    typedef volatile v4u_t __attribute__((address_space(3))) lds_vv4u;
+    lds_vint* const xflag = (lds_vint*)(smem + XFLAG_OFF);
+    if (tid < 8) xflag[tid] = 0;                                  // (ordered before any use by the barrier that opens the first stage)
+    // Tile stores, tag stores, tag polls and tile loads are all volatile accesses: the compiler keeps their program order among
+    // themselves (and the LDS executes one wave's operations in order) without a full memory barrier, which would stop it from
+    // keeping the stage's many independent operand reads in flight around them.
+    auto publish = [&](int idx, int tag) { if (lane == 0) xflag[idx] = tag; };   // after this wave's (volatile) tile store
+    auto await = [&](int idx, int tag) {
+        while (__builtin_amdgcn_readfirstlane(xflag[idx]) != tag) __builtin_amdgcn_s_sleep(1);
+    };
+    auto tile_store = [&](int off, uint2 hi, uint2 lo) {
+        *(lds_vv4u*)(smem + off + lane * 16) = v4u_t{hi.x, hi.y, lo.x, lo.y};
+    };
+    auto tile_load = [&](int off) {
+        const v4u_t f = *(lds_vv4u*)(smem + off + lane * 16);
+        return make_uint4(f.x, f.y, f.z, f.w);
+    };
     if (producer) {
         // =============== producers: operands of stage s-1 into the other buffer while stage s is consumed =====
         if (ngrp > 0) {
@@ -366,6 +396,27 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             if (grp != ngrp - 1) { __syncthreads(); continue; }
 #endif
             WKV6_T(ts0);
+            // first of all, so that it is there long before the others ask for it:
+            {   // this wave's dA tile of the stage: block wv >> 1, orientation wv & 1 (0: dA[a][b], lane col b; 1: dA^T[b][a], lane col a)
+                const char* const bb = smem + (grp & 1) * BUF_BYTES + (wv >> 1) * BBLK_BYTES;
+                f4v dA = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int off = x * RSB + (32 * s + 8 * g) * 2;
+                    const b8v gy_ = ld_b8(bb + B_GY * ARR + off), vr = ld_b8(bb + B_V * ARR + off);
+                    dA = (wv & 1) ? mfma32(vr, gy_, dA) : mfma32(gy_, vr, dA);
+                }
+                float dm[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 4 * g + q;
+                    dm[q] = ((wv & 1) ? o < x : x < o) ? dA[q] : 0.f;      // strictly lower triangle of dA in either orientation
+                }
+                uint2 th, tl;
+                split4(dm, th, tl);
+                tile_store(XT_OFF + wv * 1024, th, tl);
+                publish(wv, grp + 1);
+            }
             // stage-entry forward state: read back what this wave requested a stage ago, then request the next one.
             // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here.  It was issued a whole stage ago; the
             // drain also covers this wave's gradient stores of that stage.  (A counted wait that leaves the six stores outstanding
@@ -423,34 +474,17 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 const char* const bb = buf + blk * BBLK_BYTES;
                 float old_gr[4] = {0.f, 0.f, 0.f, 0.f};
                 fetch_old(0, ogr, grp * STG + blk * BLK + x, REV_R, 16 * wv + 4 * g, old_gr);
-                f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
-                b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: also the B operand of accr
+                b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: the B operand of accs
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int off = x * RSB + (32 * s + 8 * g) * 2;
-                    gyr[s] = ld_b8(bb + B_GY * ARR + off);
-#ifdef WKV6_ABL_DA                                               // timing-only ablation: three of the four row waves skip dA
-                    if (wv != 0) continue;
-#endif
-                    const b8v vr = ld_b8(bb + B_V * ARR + off);
-                    dA_ab = mfma32(gyr[s], vr, dA_ab);           // [row a][col b]: lane col b = x, rows a = 4g+q
-                    dA_ba = mfma32(vr, gyr[s], dA_ba);           // [row b][col a]: lane col a = x, rows b = 4g+q
-                }
+                for (int s = 0; s < 2; ++s) gyr[s] = ld_b8(bb + B_GY * ARR + x * RSB + (32 * s + 8 * g) * 2);
                 // vg_x = dA[x][x] = gy_x . v_x: the producers' two half sums
                 const float vg = *reinterpret_cast<const float*>(bb + BOFF_VG + x * 4) + *reinterpret_cast<const float*>(bb + BOFF_VG + 64 + x * 4);
                 vgs[blk] = vg;
-                float dab[4], dba[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int o = 4 * g + q;
-                    dab[q] = x < o ? dA_ab[q] : 0.f;              // dA[a = o][b = x], strictly lower
-                    dba[q] = o < x ? dA_ba[q] : 0.f;              // dA^T[b = o][a = x], strictly lower
-                }
-                uint2 th, tl;
-                split4(dab, th, tl);
-                const s4v dab_hi = __builtin_bit_cast(s4v, th), dab_lo = __builtin_bit_cast(s4v, tl);
-                split4(dba, th, tl);
-                const s4v dba_hi = __builtin_bit_cast(s4v, th), dba_lo = __builtin_bit_cast(s4v, tl);
+                await(2 * blk, grp + 1);
+                await(2 * blk + 1, grp + 1);
+                const uint4 fab = tile_load(XT_OFF + (2 * blk) * 1024), fba = tile_load(XT_OFF + (2 * blk + 1) * 1024);
+                const s4v dab_hi = __builtin_bit_cast(s4v, make_uint2(fab.x, fab.y)), dab_lo = __builtin_bit_cast(s4v, make_uint2(fab.z, fab.w));
+                const s4v dba_hi = __builtin_bit_cast(s4v, make_uint2(fba.x, fba.y)), dba_lo = __builtin_bit_cast(s4v, make_uint2(fba.z, fba.w));
                 const s4v rhf_w = tr_read(bb + B_RH * ARR + troff + 32 * wv);      // Rhat[4g+e][16wv + x]
                 const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
                 const s4v khf = tr_read(bb + B_KH * ARR + troff + 32 * wv);
@@ -610,28 +644,18 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             s4v gyT_w[SBLK], sc_hi[SBLK], sc_lo[SBLK];
             f4v accp[SBLK], Og[SBLK][4];
             {
-                f4v sc[SBLK];
-#pragma unroll
-                for (int blk = 0; blk < SBLK; ++blk) {
-                    const char* const bb = buf + blk * BBLK_BYTES;
-                    sc[blk] = f4v{0.f, 0.f, 0.f, 0.f};
+                if (wv < SBLK) {   // this wave's score tile of the stage: block wv
+                    const char* const bb = buf + wv * BBLK_BYTES;
+                    f4v sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-#ifdef WKV6_ABL_SC                                               // timing-only ablation: three of the four column waves skip the scores
-                        if (wv != 0) continue;
-#endif
                         const int off = x * RSB + (32 * s + 8 * g) * 2;
                         const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
                         const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
-                        sc[blk] = mfma32(rh, kh, sc[blk]);        // A[row a][col b]: lane col b = x, rows a = 4g+q
-                        sc[blk] = mfma32(rh, kl, sc[blk]);
-                        sc[blk] = mfma32(rl, kh, sc[blk]);
+                        sc = mfma32(rh, kh, sc);                  // A[row a][col b]: lane col b = x, rows a = 4g+q
+                        sc = mfma32(rh, kl, sc);
+                        sc = mfma32(rl, kh, sc);
                     }
-                    gyT_w[blk] = tr_read(bb + B_GY * ARR + troff + 32 * wv);      // gy[4g+e][16wv + x]
-                }
-#pragma unroll
-                for (int blk = 0; blk < SBLK; ++blk) {
-                    const char* const bb = buf + blk * BBLK_BYTES;
                     const float4 cfa = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 16 * g);
                     const float4 cfb = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 64 + 16 * g);
                     const float cf[4] = {cfa.x + cfb.x, cfa.y + cfb.y, cfa.z + cfb.z, cfa.w + cfb.w};
@@ -639,12 +663,21 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int o = 4 * g + q;                  // query token a; key token b = x
-                        scm[q] = x < o ? sc[blk][q] : (x == o ? cf[q] : 0.f);
+                        scm[q] = x < o ? sc[q] : (x == o ? cf[q] : 0.f);
                     }
                     uint2 th, tl;
                     split4(scm, th, tl);
-                    sc_hi[blk] = __builtin_bit_cast(s4v, th);
-                    sc_lo[blk] = __builtin_bit_cast(s4v, tl);
+                    tile_store(XS_OFF + wv * 1024, th, tl);
+                    publish(4 + wv, grp + 1);
+                }
+#pragma unroll
+                for (int blk = 0; blk < SBLK; ++blk) gyT_w[blk] = tr_read(buf + blk * BBLK_BYTES + B_GY * ARR + troff + 32 * wv);   // gy[4g+e][16wv + x]
+#pragma unroll
+                for (int blk = 0; blk < SBLK; ++blk) {
+                    await(4 + blk, grp + 1);
+                    const uint4 f = tile_load(XS_OFF + blk * 1024);
+                    sc_hi[blk] = __builtin_bit_cast(s4v, make_uint2(f.x, f.y));
+                    sc_lo[blk] = __builtin_bit_cast(s4v, make_uint2(f.z, f.w));
                 }
 #pragma unroll
                 for (int blk = 0; blk < SBLK; ++blk) {
