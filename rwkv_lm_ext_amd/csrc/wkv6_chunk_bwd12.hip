@@ -49,7 +49,7 @@ constexpr int STG = 32, SBLK = STG / BLK;                             // tokens 
 constexpr int BUF_BYTES = SBLK * BBLK_BYTES;                           // one stage image; two of them
 constexpr int CKQ_OFF = 2 * BUF_BYTES;                                 // float [4 row waves][16][64]: next stage's checkpoint (LDS-DMA)
 // Tiles that every row wave (dA, both orientations, per block) and every column wave (masked scores per block) needs are computed
-// ONCE per workgroup and handed over as MFMA fragments: row wave w makes dA tile w (block w >> 1, orientation w & 1), column waves 0
+// ONCE per workgroup and handed over as MFMA fragments: row waves 2 and 3 make the dA tiles of blocks 0 and 1 (both orientations), column waves 0
 // and 1 make the score tiles of blocks 0 and 1.  The waves of a role are not synchronised inside a stage, so each tile carries a tag
 // (stage index + 1) that its readers poll; the tags live in the unused padding of the first image row.
 constexpr int XT_OFF = CKQ_OFF + 4 * 4096;                             // uint4 [4 tiles][64 lanes]  dA fragments: bf16x4 hi | bf16x4 lo
@@ -397,25 +397,33 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
 #endif
             WKV6_T(ts0);
             // first of all, so that it is there long before the others ask for it:
-            {   // this wave's dA tile of the stage: block wv >> 1, orientation wv & 1 (0: dA[a][b], lane col b; 1: dA^T[b][a], lane col a)
-                const char* const bb = smem + (grp & 1) * BUF_BYTES + (wv >> 1) * BBLK_BYTES;
-                f4v dA = {0.f, 0.f, 0.f, 0.f};
+            if (wv >= 2) {   // this wave's dA tiles of the stage: block wv - 2, both orientations (tile 2 blk: dA[a][b], lane col b; 2 blk + 1:
+                             // dA^T[b][a], lane col a) from one pair of operand reads.  Row waves 0 and 1 make none: their SIMDs host the
+                             // column waves that make the score tiles.
+                const int tb = wv - 2;
+                const char* const bb = smem + (grp & 1) * BUF_BYTES + tb * BBLK_BYTES;
+                f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int off = x * RSB + (32 * s + 8 * g) * 2;
                     const b8v gy_ = ld_b8(bb + B_GY * ARR + off), vr = ld_b8(bb + B_V * ARR + off);
-                    dA = (wv & 1) ? mfma32(vr, gy_, dA) : mfma32(gy_, vr, dA);
+                    dA_ab = mfma32(gy_, vr, dA_ab);              // [row a][col b]: lane col b = x, rows a = 4g+q
+                    dA_ba = mfma32(vr, gy_, dA_ba);              // [row b][col a]: lane col a = x, rows b = 4g+q
                 }
-                float dm[4];
+                float dab[4], dba[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int o = 4 * g + q;
-                    dm[q] = ((wv & 1) ? o < x : x < o) ? dA[q] : 0.f;      // strictly lower triangle of dA in either orientation
+                    dab[q] = x < o ? dA_ab[q] : 0.f;              // dA[a = o][b = x], strictly lower
+                    dba[q] = o < x ? dA_ba[q] : 0.f;              // dA^T[b = o][a = x], strictly lower
                 }
                 uint2 th, tl;
-                split4(dm, th, tl);
-                tile_store(XT_OFF + wv * 1024, th, tl);
-                publish(wv, grp + 1);
+                split4(dab, th, tl);
+                tile_store(XT_OFF + (2 * tb) * 1024, th, tl);
+                publish(2 * tb, grp + 1);
+                split4(dba, th, tl);
+                tile_store(XT_OFF + (2 * tb + 1) * 1024, th, tl);
+                publish(2 * tb + 1, grp + 1);
             }
             // stage-entry forward state: read back what this wave requested a stage ago, then request the next one.
             // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here.  It was issued a whole stage ago; the
