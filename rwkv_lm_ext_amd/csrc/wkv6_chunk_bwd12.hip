@@ -37,8 +37,8 @@ using namespace chunk;
 enum { B_RH = 0, B_RL, B_KH, B_KL, B_V, B_GY, B_R, B_K, NB_ARR };      // bf16 [16][RSB/2] each
 constexpr int FRS = 72 * 4;                                            // bytes per fp32 token row (conflict-free float4 row reads)
 constexpr int BOFF_FR = NB_ARR * ARR;                                  // float [16][72]  fR_a = e^{c_a - c_8}
-constexpr int BOFF_FK = BOFF_FR + BLK * FRS;                           // float [16][72]  fK_a = e^{c_8 - c_{a+1}}
-constexpr int BOFF_LW = BOFF_FK + BLK * FRS;                           // float [16][72]  lw_a e^{lw_a - max(lw_a, LW_MIN)}
+// (no fK array: fK_b = e^{c_8 - c_{b+1}} = 1 / fR_{b+1}, with fR_16 = E16m8 -- the row waves read fR one token further and take the reciprocal)
+constexpr int BOFF_LW = BOFF_FR + BLK * FRS;                           // float [16][72]  lw_a e^{lw_a - max(lw_a, LW_MIN)}
 constexpr int BOFF_E8 = BOFF_LW + BLK * FRS;                           // float [64]
 constexpr int BOFF_E16 = BOFF_E8 + 256;
 constexpr int BOFF_E16M8 = BOFF_E16 + 256;
@@ -55,7 +55,16 @@ constexpr int CKQ_OFF = 2 * BUF_BYTES;                                 // float 
 constexpr int XT_OFF = CKQ_OFF + 4 * 4096;                             // uint4 [4 tiles][64 lanes]  dA fragments: bf16x4 hi | bf16x4 lo
 constexpr int XS_OFF = XT_OFF + 4 * 1024;                              // uint4 [2 tiles][64 lanes]  score fragments
 constexpr int XFLAG_OFF = 128;                                         // int [6] in the padding of row 0 of the first array of buffer 0
-constexpr int BWD12_LDS = XS_OFF + 2 * 1024;
+// G once per workgroup (GONCE kernels, i.e. unsplit launches): the column waves own the adjoint state and publish the operand the
+// row waves need, (E16m8 (.) G) split into bf16 hi | lo, stored [value column j][key row i] with 144-byte rows, twice per stage (for
+// block 1, then for block 0: one buffer, tags GA "block 1's version is there" / GB "taken" / GC "block 0's version is there"); the
+// row waves take it with transposing reads instead of carrying, updating, scaling and splitting a second copy of G by rows.  The
+// column waves run the stage's G recurrence first thing, the row waves need its products last: nobody waits.  The space is what the
+// fK arrays used to occupy.
+constexpr int GRS = 144;                                               // bytes per row of the published operand
+constexpr int GOP_OFF = XS_OFF + 2 * 1024;                             // bf16 [2 (hi | lo)][64][GRS / 2]
+constexpr int TAG_DA = 0, TAG_SC = 4, TAG_GA = 8, TAG_GB = 12, TAG_GC = 16, N_TAGS = 20;   // tag slots (see xflag)
+constexpr int BWD12_LDS = GOP_OFF + 2 * HEAD * GRS;
 
 // One step of four independent in-row suffix sums: x[q] += x[q] of the lane `ctrl` names (lanes without a source keep their
 // value: DPP disables them).  Single v_add_f32_dpp instructions (the builtin gives v_mov_dpp + v_add).  A VALU write of a VGPR
@@ -85,7 +94,8 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 // every store (plain backward 0.48 -> 0.58 ms; the first half of wkv6_bi paid the same until it got its own instantiation).
 // (The kernel proper is a device function of (arguments, workgroup slot) so that chunk_bwd12_pair_kernel can run it on one of two
 // argument blocks: SURVEY.md row n2.)
-template <bool W_RAW, int GEN>
+// GONCE: the row and column roles share a workgroup (a.split == 0) and G exists once (see GOP_OFF).
+template <bool W_RAW, int GEN, bool GONCE>
 __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsigned slot)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][BBLK_BYTES] | checkpoint queue
@@ -173,8 +183,10 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             const unsigned ig = (unsigned)(tokmap(p, REV_Y) * a.C + ch0);
             pr[tt] = buf_load8(rs_r, ir * 2u);
             pk[tt] = buf_load8(rs_k, ik * 2u);
-            pv[tt] = buf_load8(rs_v, iv * 2u);
-            pg[tt] = buf_load8(rs_g, ig * 2u);
+            if constexpr (!GONCE) {                            // (GONCE: the column waves fetch and copy v, gy)
+                pv[tt] = buf_load8(rs_v, iv * 2u);
+                pg[tt] = buf_load8(rs_g, ig * 2u);
+            }
             if constexpr (W_RAW) pw[tt] = buf_load8(rs_w, iw * 2u);
             else pe[tt] = buf_load16f(rs_w, iw * 4u);
         }
@@ -216,19 +228,21 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             part += dpp_mov<DPP_SHL4>(part);
             const int tok = 2 * tq + tt;
             char* const row = bb + tok * RSB + ch0 * 2;
-            // vg_a = gy_a . v_a, this half's 32 channels (exact bf16 products, fp32 sums): the row waves' diagonal of dA
-            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-            float pvg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pg[tt].x), __builtin_bit_cast(bf2, pv[tt].x), 0.f, false);
-            pvg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pg[tt].y), __builtin_bit_cast(bf2, pv[tt].y), pvg, false);
-            pvg += dpp_mov<DPP_XOR1>(pvg);
-            pvg += dpp_mov<DPP_XOR2>(pvg);
-            pvg += dpp_mov<DPP_SHL4>(pvg);
-            if (c8i == 0) {
-                *reinterpret_cast<float*>(bb + BOFF_COEF + (half * 16 + tok) * 4) = part;
-                *reinterpret_cast<float*>(bb + BOFF_VG + (half * 16 + tok) * 4) = pvg;
+            if (c8i == 0) *reinterpret_cast<float*>(bb + BOFF_COEF + (half * 16 + tok) * 4) = part;
+            if constexpr (!GONCE) {
+                // vg_a = gy_a . v_a, this half's 32 channels (exact bf16 products, fp32 sums): the row waves' diagonal of dA.
+                // (GONCE: the column waves do this part of the preparation, col_copy below -- with G held once they have the
+                // slack and the producers are the critical path of a stage.)
+                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                float pvg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pg[tt].x), __builtin_bit_cast(bf2, pv[tt].x), 0.f, false);
+                pvg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pg[tt].y), __builtin_bit_cast(bf2, pv[tt].y), pvg, false);
+                pvg += dpp_mov<DPP_XOR1>(pvg);
+                pvg += dpp_mov<DPP_XOR2>(pvg);
+                pvg += dpp_mov<DPP_SHL4>(pvg);
+                if (c8i == 0) *reinterpret_cast<float*>(bb + BOFF_VG + (half * 16 + tok) * 4) = pvg;
+                *reinterpret_cast<uint2*>(row + B_V * ARR) = pv[tt];
+                *reinterpret_cast<uint2*>(row + B_GY * ARR) = pg[tt];
             }
-            *reinterpret_cast<uint2*>(row + B_V * ARR) = pv[tt];
-            *reinterpret_cast<uint2*>(row + B_GY * ARR) = pg[tt];
             // raw r, k: only read as (token x, 4 channels) uint2 by the row waves; tokens >= 8 keep their 16-byte units swapped
             // in pairs so that rows x and x + 8 (same bank at the 160-B stride) do not collide in that read
             char* const rowz = bb + tok * RSB + ((ch0 * 2) ^ ((tok & 8) << 1));
@@ -282,7 +296,6 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             split4(kh, hi, lo);
             *reinterpret_cast<uint2*>(row + B_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + B_KL * ARR) = lo;
             *reinterpret_cast<float4*>(bb + BOFF_FR + tok * FRS + ch0 * 4) = make_float4(fr[0], fr[1], fr[2], fr[3]);
-            *reinterpret_cast<float4*>(bb + BOFF_FK + tok * FRS + ch0 * 4) = make_float4(fk[0], fk[1], fk[2], fk[3]);
         }
     };
 
@@ -297,14 +310,32 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
     typedef volatile int __attribute__((address_space(3))) lds_vint;
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     typedef volatile v4u_t __attribute__((address_space(3))) lds_vv4u;
-    lds_vint* const xflag = (lds_vint*)(smem + XFLAG_OFF);
-    if (tid < 8) xflag[tid] = 0;                                  // (ordered before any use by the barrier that opens the first stage)
+    // tag slot idx: the padding (bytes 128..159) of image rows 0, 1, 2 of the first array, eight per row
+    auto xflag_at = [&](int idx) { return (lds_vint*)(smem + (idx >> 3) * RSB + XFLAG_OFF + (idx & 7) * 4); };
+    if (tid < N_TAGS + 4) *xflag_at(tid) = 0;                     // (ordered before any use by the barrier that opens the first stage)
     // Tile stores, tag stores, tag polls and tile loads are all volatile accesses: the compiler keeps their program order among
     // themselves (and the LDS executes one wave's operations in order) without a full memory barrier, which would stop it from
     // keeping the stage's many independent operand reads in flight around them.
-    auto publish = [&](int idx, int tag) { if (lane == 0) xflag[idx] = tag; };   // after this wave's (volatile) tile store
+    auto publish = [&](int idx, int tag) { if (lane == 0) *xflag_at(idx) = tag; };   // after this wave's (volatile) tile store
     auto await = [&](int idx, int tag) {
-        while (__builtin_amdgcn_readfirstlane(xflag[idx]) != tag) __builtin_amdgcn_s_sleep(1);
+        while (__builtin_amdgcn_readfirstlane(*xflag_at(idx)) != tag) __builtin_amdgcn_s_sleep(1);
+    };
+    // two / four adjacent tags with one LDS round trip (a poll costs an LDS latency plus a drain of the wave's LDS queue)
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    auto await2 = [&](int idx, int tag) {
+        for (;;) {
+            const v2u_t f = *(volatile v2u_t __attribute__((address_space(3)))*)xflag_at(idx);
+            if (__builtin_amdgcn_readfirstlane((int)((f.x ^ (unsigned)tag) | (f.y ^ (unsigned)tag))) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto await4 = [&](int idx, int tag) {
+        for (;;) {
+            const v4u_t f = *(lds_vv4u*)xflag_at(idx);
+            const unsigned t = (unsigned)tag;
+            if (__builtin_amdgcn_readfirstlane((int)((f.x ^ t) | (f.y ^ t) | (f.z ^ t) | (f.w ^ t))) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
     };
     auto tile_store = [&](int off, uint2 hi, uint2 lo) {
         *(lds_vv4u*)(smem + off + lane * 16) = v4u_t{hi.x, hi.y, lo.x, lo.y};
@@ -420,10 +451,10 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 uint2 th, tl;
                 split4(dab, th, tl);
                 tile_store(XT_OFF + (2 * tb) * 1024, th, tl);
-                publish(2 * tb, grp + 1);
+                publish(TAG_DA + 2 * tb, grp + 1);
                 split4(dba, th, tl);
                 tile_store(XT_OFF + (2 * tb + 1) * 1024, th, tl);
-                publish(2 * tb + 1, grp + 1);
+                publish(TAG_DA + 2 * tb + 1, grp + 1);
             }
             // stage-entry forward state: read back what this wave requested a stage ago, then request the next one.
             // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here.  It was issued a whole stage ago; the
@@ -472,6 +503,31 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (grp > 0) request_ckpt(grp - 1);
             WKV6_T(ts2);
+            // ---- (GONCE) G-dependent part of gk, decoupled from the epilogues: sum_j (E16m8 G)[i][j] v_b[j] per block from the operand
+            //      the column waves publish; block 1's version is taken (and released: GB) here, block 0's behind the pre-phase
+            f4v gvb[SBLK];
+            auto take_gop = [&](int blk) {
+                int base = GOP_OFF + (8 * g + (x >> 2)) * GRS + (16 * wv + 4 * (x & 3)) * 2;
+                asm volatile("" : "+v"(base));                     // keeps the reads behind the tag polls that precede the call
+                typedef short s8v __attribute__((ext_vector_type(8)));
+                f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {   // lane (x, g): key row 16wv + x, value columns 32s + 8g .. +7 (stored [j][i]: transposing reads)
+                    const char* const ph = smem + base + 32 * s * GRS;
+                    const s8v h8 = __builtin_shufflevector(tr_read(ph), tr_read(ph + 4 * GRS), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s8v l8 = __builtin_shufflevector(tr_read(ph + HEAD * GRS), tr_read(ph + HEAD * GRS + 4 * GRS), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const b8v vr = ld_b8(buf + blk * BBLK_BYTES + B_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
+                    acc = mfma32(__builtin_bit_cast(b8v, h8), vr, acc);
+                    acc = mfma32(__builtin_bit_cast(b8v, l8), vr, acc);
+                }
+                return acc;
+            };
+            if constexpr (GONCE) {
+                await4(TAG_GA, grp + 1);
+                gvb[1] = take_gop(1);
+                asm volatile("" :: "v"(gvb[1]));                   // (the operand reads have returned)
+                publish(TAG_GB + wv, grp + 1);
+            }
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
             //      Four independent blocks => many instructions in flight.
@@ -488,8 +544,7 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 // vg_x = dA[x][x] = gy_x . v_x: the producers' two half sums
                 const float vg = *reinterpret_cast<const float*>(bb + BOFF_VG + x * 4) + *reinterpret_cast<const float*>(bb + BOFF_VG + 64 + x * 4);
                 vgs[blk] = vg;
-                await(2 * blk, grp + 1);
-                await(2 * blk + 1, grp + 1);
+                await2(TAG_DA + 2 * blk, grp + 1);
                 const uint4 fab = tile_load(XT_OFF + (2 * blk) * 1024), fba = tile_load(XT_OFF + (2 * blk + 1) * 1024);
                 const s4v dab_hi = __builtin_bit_cast(s4v, make_uint2(fab.x, fab.y)), dab_lo = __builtin_bit_cast(s4v, make_uint2(fab.z, fab.w));
                 const s4v dba_hi = __builtin_bit_cast(s4v, make_uint2(fba.x, fba.y)), dba_lo = __builtin_bit_cast(s4v, make_uint2(fba.z, fba.w));
@@ -543,6 +598,10 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 }
             }
             WKV6_T(ts3);
+            if constexpr (GONCE) {
+                await4(TAG_GC, grp + 1);
+                gvb[0] = take_gop(0);
+            }
             // ---- chain: only the work that needs G
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
@@ -555,7 +614,8 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 fetch_old(3, ogw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw);
                 // (gy^T Rhat) tiles of the G update: independent of G, issued first so they run under the chain's latency
                 f4v Oi[4];
-                {
+                f4v acck = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (!GONCE) {
                     const s4v rhf_w = tr_read(bb + B_RH * ARR + troff + 32 * wv);  // Rhat[4g+e][16wv + x]
                     const s4v rlf_w = tr_read(bb + B_RL * ARR + troff + 32 * wv);
 #pragma unroll
@@ -566,23 +626,26 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                         o = mfma16(gyf, rlf_w, o);
                         Oi[jt] = o;
                     }
-                }
-                f4v acck = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const b8v vr = ld_b8(bb + B_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
-                    float t0[4], t1[4];
-                    b8v hi, lo;
+                    for (int s = 0; s < 2; ++s) {
+                        const b8v vr = ld_b8(bb + B_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
+                        float t0[4], t1[4];
+                        b8v hi, lo;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
-                    split8(t0, t1, hi, lo);
-                    acck = mfma32(hi, vr, acck);
-                    acck = mfma32(lo, vr, acck);
+                        for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
+                        split8(t0, t1, hi, lo);
+                        acck = mfma32(hi, vr, acck);
+                        acck = mfma32(lo, vr, acck);
+                    }
+                } else {
+                    acck = gvb[blk];
                 }
                 acck += ackp[blk];
                 {
                     const int ch = 16 * wv + 4 * g;
-                    const float4 fk4 = *reinterpret_cast<const float4*>(bb + BOFF_FK + x * FRS + ch * 4);
+                    const float4 fn4 = *reinterpret_cast<const float4*>(x < 15 ? bb + BOFF_FR + (x + 1) * FRS + ch * 4 : bb + BOFF_E16M8 + ch * 4);
+                    const float4 fk4 = make_float4(__builtin_amdgcn_rcpf(fn4.x), __builtin_amdgcn_rcpf(fn4.y), __builtin_amdgcn_rcpf(fn4.z),
+                                                   __builtin_amdgcn_rcpf(fn4.w));      // fK_x = 1 / fR_{x+1}
                     const float4 lw4 = *reinterpret_cast<const float4*>(bb + BOFF_LW + x * FRS + ch * 4);
                     const uint2 rr = *reinterpret_cast<const uint2*>(bb + B_R * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
                     const uint2 kk = *reinterpret_cast<const uint2*>(bb + B_K * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
@@ -614,10 +677,12 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                     emit(3, rs_gw, ogw, p, REV_W, ch, o_gw, old_gw);
                 }
                 // ---- G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
+                if constexpr (!GONCE) {
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
+                    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * Oi[jt][q]);
+                        for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * Oi[jt][q]);
+                }
             }
             WKV6_T(ts4);
             __syncthreads();
@@ -640,17 +705,95 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
         f4v GJ[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) GJ[t] = f4v{0.f, 0.f, 0.f, 0.f};
+        // (GONCE) this wave's share of the PREPARATION: v and gy of tokens 4wv .. 4wv+3 of both blocks of the stage being prepared go
+        // from global memory into the other buffer's images, with the two half sums of vg_a = gy_a . v_a.  lane = (token tl, channels 4cl .. 4cl+3); requested at the head of a stage, written at its end.
+        const int tl = lane >> 4, cl = lane & 15;
+        uint2 cv[SBLK], cg[SBLK];
+        auto col_load = [&](int stg) {
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                const int p = stg * STG + blk * BLK + 4 * wv + tl;
+                cv[blk] = buf_load8(rs_v, (unsigned)(tokmap(p, REV_V) * a.C + 4 * cl) * 2u);
+                cg[blk] = buf_load8(rs_g, (unsigned)(tokmap(p, REV_Y) * a.C + 4 * cl) * 2u);
+            }
+        };
+        auto col_copy = [&](int stg) {
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                char* const bb = smem + (stg & 1) * BUF_BYTES + blk * BBLK_BYTES;
+                const int tok = 4 * wv + tl;
+                *reinterpret_cast<uint2*>(bb + B_V * ARR + tok * RSB + 8 * cl) = cv[blk];
+                *reinterpret_cast<uint2*>(bb + B_GY * ARR + tok * RSB + 8 * cl) = cg[blk];
+                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                float vg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, cg[blk].x), __builtin_bit_cast(bf2, cv[blk].x), 0.f, false);
+                vg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, cg[blk].y), __builtin_bit_cast(bf2, cv[blk].y), vg, false);
+                vg += dpp_mov<DPP_XOR1>(vg);                       // the two 32-channel half sums, formed exactly as the producers of the
+                vg += dpp_mov<DPP_XOR2>(vg);                       // split kernels form them (same results bit for bit)
+                vg += dpp_mov<DPP_SHL4>(vg);
+                if ((cl & 7) == 0) *reinterpret_cast<float*>(bb + BOFF_VG + ((cl >> 3) * 16 + tok) * 4) = vg;
+            }
+        };
+        if (GONCE && ngrp > 0) {
+            col_load(ngrp - 1);
+            col_copy(ngrp - 1);
+        }
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
 #ifdef WKV6_ABL_NOCOL                                              // timing-only ablation: column waves only keep the barrier count
             if (grp != ngrp - 1) { __syncthreads(); continue; }
 #endif
             WKV6_T(ts0);
+            if (GONCE && grp > 0) col_load(grp - 1);
             const char* const buf = smem + (grp & 1) * BUF_BYTES;
             // ---- pre-phase: everything that does not depend on G, stage-major over the 4 blocks so that many
             //      independent LDS reads / MFMAs are in flight (blocks past the end of the sequence are neutral)
             s4v gyT_w[SBLK], sc_hi[SBLK], sc_lo[SBLK];
             f4v accp[SBLK], Og[SBLK][4];
+            // (GONCE) the stage's G recurrence, first thing: per block (1, then 0) scale by E16m8, split, publish the operand for the row
+            // waves (stored [j][i]: this lane's 16 bytes are key rows 32s + 8g .. +7 of value column 16wv + x), keep the fragments for
+            // this wave's own chain, and move G to the entry of the block
+            b8v gh[SBLK][2], gl[SBLK][2];
+            if constexpr (GONCE) {
+#pragma unroll
+                for (int blk = SBLK - 1; blk >= 0; --blk) {
+                    const char* const bb = buf + blk * BBLK_BYTES;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float t0[4], t1[4];
+                        const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g) * 4);
+                        const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
+                        t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
+                        t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
+                        t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
+                        split8(t0, t1, gh[blk][s], gl[blk][s]);
+                    }
+                    if (blk == 0) {
+                        await4(TAG_GB, grp + 1);     // the row waves have taken block 1's version
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        char* const dst = smem + GOP_OFF + (16 * wv + x) * GRS + (32 * s + 8 * g) * 2;
+                        *(lds_vv4u*)dst = __builtin_bit_cast(v4u_t, gh[blk][s]);
+                        *(lds_vv4u*)(dst + HEAD * GRS) = __builtin_bit_cast(v4u_t, gl[blk][s]);
+                    }
+                    publish((blk ? TAG_GA : TAG_GC) + wv, grp + 1);
+                    const s4v gyT = tr_read(bb + B_GY * ARR + troff + 32 * wv);           // gy[4g+e][16wv + x]
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {              // (Rhat^T gy) tile [row i_local][col j_local = x];  G <- E16 G + E8 (Rhat^T gy)
+                        const s4v rhf = tr_read(bb + B_RH * ARR + trow + tile_tr(it));
+                        const s4v rlf = tr_read(bb + B_RL * ARR + trow + tile_tr(it));
+                        f4v o = {0.f, 0.f, 0.f, 0.f};
+                        o = mfma16(rhf, gyT, o);
+                        o = mfma16(rlf, gyT, o);
+                        const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (tile_ch(it) + 8 * g) * 4);
+                        const float4 d8 = *reinterpret_cast<const float4*>(bb + BOFF_E8 + (tile_ch(it) + 8 * g) * 4);
+                        GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * o[0]);
+                        GJ[it][1] = fmaf(d16.y, GJ[it][1], d8.y * o[1]);
+                        GJ[it][2] = fmaf(d16.z, GJ[it][2], d8.z * o[2]);
+                        GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * o[3]);
+                    }
+                }
+            }
             {
                 if (wv < SBLK) {   // this wave's score tile of the stage: block wv
                     const char* const bb = buf + wv * BBLK_BYTES;
@@ -676,13 +819,13 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                     uint2 th, tl;
                     split4(scm, th, tl);
                     tile_store(XS_OFF + wv * 1024, th, tl);
-                    publish(4 + wv, grp + 1);
+                    publish(TAG_SC + wv, grp + 1);
                 }
 #pragma unroll
                 for (int blk = 0; blk < SBLK; ++blk) gyT_w[blk] = tr_read(buf + blk * BBLK_BYTES + B_GY * ARR + troff + 32 * wv);   // gy[4g+e][16wv + x]
 #pragma unroll
                 for (int blk = 0; blk < SBLK; ++blk) {
-                    await(4 + blk, grp + 1);
+                    await(TAG_SC + blk, grp + 1);
                     const uint4 f = tile_load(XS_OFF + blk * 1024);
                     sc_hi[blk] = __builtin_bit_cast(s4v, make_uint2(f.x, f.y));
                     sc_lo[blk] = __builtin_bit_cast(s4v, make_uint2(f.z, f.w));
@@ -694,6 +837,7 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                     acc = mfma16(gyT_w[blk], sc_hi[blk], acc);
                     acc = mfma16(gyT_w[blk], sc_lo[blk], acc);
                     accp[blk] = acc;
+                    if constexpr (!GONCE)
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {              // (Rhat^T gy) tile: [row i_local][col j_local = x]
                         const s4v rhf = tr_read(bb + B_RH * ARR + trow + tile_tr(it));
@@ -713,21 +857,32 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 float old_gv[4] = {0.f, 0.f, 0.f, 0.f};
                 fetch_old(2, ogv, grp * STG + blk * BLK + x, REV_V, 16 * wv + 4 * g, old_gv);
                 f4v acc = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (GONCE) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int off = x * RSB + (32 * s + 8 * g) * 2;
-                    const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
-                    float t0[4], t1[4];
-                    const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g) * 4);
-                    const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
-                    t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
-                    t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
-                    t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
-                    b8v gh, gl;
-                    split8(t0, t1, gh, gl);
-                    acc = mfma32(gh, kh, acc);                   // k-slot (s, g, e) <-> key channel 32s + 8g + e
-                    acc = mfma32(gh, kl, acc);
-                    acc = mfma32(gl, kh, acc);
+                    for (int s = 0; s < 2; ++s) {
+                        const int off = x * RSB + (32 * s + 8 * g) * 2;
+                        const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
+                        acc = mfma32(gh[blk][s], kh, acc);       // k-slot (s, g, e) <-> key channel 32s + 8g + e
+                        acc = mfma32(gh[blk][s], kl, acc);
+                        acc = mfma32(gl[blk][s], kh, acc);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int off = x * RSB + (32 * s + 8 * g) * 2;
+                        const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
+                        float t0[4], t1[4];
+                        const float4 m0 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g) * 4);
+                        const float4 m1 = *reinterpret_cast<const float4*>(bb + BOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
+                        t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
+                        t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
+                        t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
+                        b8v gh_, gl_;
+                        split8(t0, t1, gh_, gl_);
+                        acc = mfma32(gh_, kh, acc);              // k-slot (s, g, e) <-> key channel 32s + 8g + e
+                        acc = mfma32(gh_, kl, acc);
+                        acc = mfma32(gl_, kh, acc);
+                    }
                 }
                 acc += accp[blk];
                 {
@@ -736,6 +891,7 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                     emit(2, rs_gv, ogv, p, REV_V, 16 * wv + 4 * g, o, old_gv);
                 }
                 // ---- G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
+                if constexpr (!GONCE)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const float4 d16 = *reinterpret_cast<const float4*>(bb + BOFF_E16 + (tile_ch(it) + 8 * g) * 4);
@@ -746,6 +902,7 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                     GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * Og[blk][it][3]);
                 }
             }
+            if (GONCE && grp > 0) col_copy(grp - 1);
             WKV6_T(ts2);
             __syncthreads();
             WKV6_T(ts3);
@@ -784,10 +941,10 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
     }
 }
 
-template <bool W_RAW, int GEN>
+template <bool W_RAW, int GEN, bool GONCE>
 __global__ __launch_bounds__(768) void chunk_bwd12_kernel(const ScanArgs a)
 {
-    chunk_bwd12_body<W_RAW, GEN>(a, blockIdx.x);
+    chunk_bwd12_body<W_RAW, GEN, GONCE>(a, blockIdx.x);
 }
 
 // the backward of chunk_fwd_pair_kernel (wkv6_chunk.hip): two problems of one shape, slots [0, B H) serve a0, the rest a1
@@ -796,7 +953,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12_pair_kernel(const ScanArgs a0
 {
     const unsigned n = (unsigned)(a0.B * a0.H);
     const bool second = blockIdx.x >= n;
-    chunk_bwd12_body<W_RAW, 0>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);
+    chunk_bwd12_body<W_RAW, 0, true>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);
 }
 
 template <bool W_RAW, int GEN> hipError_t launch_bwd12_inst(const ScanArgs& a, hipStream_t st)
@@ -804,9 +961,14 @@ template <bool W_RAW, int GEN> hipError_t launch_bwd12_inst(const ScanArgs& a, h
     constexpr size_t lds = BWD12_LDS;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static LdsAttrOnce attr;                   // per instantiation and device
-    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW, GEN>), lds)) return e;
-    if (a.split) hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW, GEN>), dim3(2 * a.B * a.H), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW, GEN>), dim3(a.B * a.H), dim3(768), lds, st, a);
+    static LdsAttrOnce attr_split;
+    if (a.split) {
+        if (hipError_t e = attr_split.ensure(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW, GEN, false>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW, GEN, false>), dim3(2 * a.B * a.H), dim3(512), lds, st, a);
+    } else {
+        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12_kernel<W_RAW, GEN, true>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12_kernel<W_RAW, GEN, true>), dim3(a.B * a.H), dim3(768), lds, st, a);
+    }
     return hipGetLastError();
 }
 template <bool W_RAW> hipError_t launch_bwd12_variant(const ScanArgs& a, hipStream_t st)
