@@ -169,8 +169,11 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
     float uu[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + ch0, uu);
 
+    // two register sets: the loads of stage s-2 are in flight (n*) while stage s-1 is prepared from the set taken over (p*)
     uint2 pr[2], pk[2], pv[2], pg[2], pw[2];
     float4 pe[2];
+    uint2 nr[2], nk[2], nv[2], ng[2], nw[2];
+    float4 ne[2];
     const rsrc_t rs_r = make_rsrc(gr_, nbytes), rs_k = make_rsrc(gk_, nbytes), rs_v = make_rsrc(gv_, nbytes), rs_g = make_rsrc(ggy, nbytes);
     const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, nbytes)
                               : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? (unsigned)(ntok - 1) * a.C * 4u + 256u : 0u);
@@ -181,17 +184,31 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             const unsigned ir = (unsigned)(tokmap(p, REV_R) * a.C + ch0), ik = (unsigned)(tokmap(p, REV_K) * a.C + ch0);
             const unsigned iv = (unsigned)(tokmap(p, REV_V) * a.C + ch0), iw = (unsigned)(tokmap(p, REV_W) * a.C + ch0);
             const unsigned ig = (unsigned)(tokmap(p, REV_Y) * a.C + ch0);
-            pr[tt] = buf_load8(rs_r, ir * 2u);
-            pk[tt] = buf_load8(rs_k, ik * 2u);
+            nr[tt] = buf_load8(rs_r, ir * 2u);
+            nk[tt] = buf_load8(rs_k, ik * 2u);
             if constexpr (!GONCE) {                            // (GONCE: the column waves fetch and copy v, gy)
-                pv[tt] = buf_load8(rs_v, iv * 2u);
-                pg[tt] = buf_load8(rs_g, ig * 2u);
+                nv[tt] = buf_load8(rs_v, iv * 2u);
+                ng[tt] = buf_load8(rs_g, ig * 2u);
             }
-            if constexpr (W_RAW) pw[tt] = buf_load8(rs_w, iw * 2u);
-            else pe[tt] = buf_load16f(rs_w, iw * 4u);
+            if constexpr (W_RAW) nw[tt] = buf_load8(rs_w, iw * 2u);
+            else ne[tt] = buf_load16f(rs_w, iw * 4u);
         }
     };
 
+    auto take_group = [&]() {          // the loaded set becomes the working set (register moves: the next loads may then overwrite n*)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            pr[tt] = nr[tt]; pk[tt] = nk[tt];
+            if constexpr (!GONCE) { pv[tt] = nv[tt]; pg[tt] = ng[tt]; }
+            if constexpr (W_RAW) pw[tt] = nw[tt]; else pe[tt] = ne[tt];
+        }
+        if constexpr (W_RAW)
+            asm volatile("" : "+v"(pr[0].x), "+v"(pr[0].y), "+v"(pr[1].x), "+v"(pr[1].y), "+v"(pk[0].x), "+v"(pk[0].y), "+v"(pk[1].x), "+v"(pk[1].y),
+                              "+v"(pw[0].x), "+v"(pw[0].y), "+v"(pw[1].x), "+v"(pw[1].y));
+        else
+            asm volatile("" : "+v"(pr[0].x), "+v"(pr[0].y), "+v"(pr[1].x), "+v"(pr[1].y), "+v"(pk[0].x), "+v"(pk[0].y), "+v"(pk[1].x), "+v"(pk[1].y),
+                              "+v"(pe[0].x), "+v"(pe[0].y), "+v"(pe[0].z), "+v"(pe[0].w), "+v"(pe[1].x), "+v"(pe[1].y), "+v"(pe[1].z), "+v"(pe[1].w));
+    };
     auto prep_group = [&](int grp) {
         char* const bb = smem + (grp & 1) * BUF_BYTES + pb * BBLK_BYTES;
         float r[2][4], k[2][4], cs[2][4], lws[2][4];
@@ -348,22 +365,23 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
         // =============== producers: operands of stage s-1 into the other buffer while stage s is consumed =====
         if (ngrp > 0) {
             load_group(ngrp - 1);
-            prep_group(ngrp - 1);
+            take_group();
             if (ngrp > 1) load_group(ngrp - 2);
+            prep_group(ngrp - 1);
         }
         __syncthreads();
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             WKV6_T(ts0);
 #ifdef WKV6_STAMP
-            asm volatile("" :: "v"(pr[0].x), "v"(pk[0].x), "v"(pv[0].x), "v"(pg[0].x), "v"(pw[0].x), "v"(pr[1].x), "v"(pk[1].x),
-                         "v"(pv[1].x), "v"(pg[1].x), "v"(pw[1].x));      // wait for the loads here
+            asm volatile("" :: "v"(nr[0].x), "v"(nk[0].x), "v"(nr[1].x), "v"(nk[1].x));      // wait for the loads here
 #endif
             WKV6_T(ts1);
 #ifndef WKV6_ABL_NOPROD                                            // timing-only ablation: the stage images are prepared once
             if (grp > 0) {
-                prep_group(grp - 1);
+                take_group();                                      // stage s-1's inputs (requested a whole stage ago)
+                if (grp > 1) load_group(grp - 2);                  // the next request first: it flies during the whole preparation
                 WKV6_T(ts2);
-                if (grp > 1) load_group(grp - 2);
+                prep_group(grp - 1);
             }
 #endif
             WKV6_T(ts3);
@@ -455,6 +473,32 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 split4(dba, th, tl);
                 tile_store(XT_OFF + (2 * tb + 1) * 1024, th, tl);
                 publish(TAG_DA + 2 * tb + 1, grp + 1);
+            }
+            if (GONCE && wv < SBLK) {   // row waves 0 and 1: the masked score tile of block wv, for the column waves (the busier role)
+                const char* const bb = smem + (grp & 1) * BUF_BYTES + wv * BBLK_BYTES;
+                f4v sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int off = x * RSB + (32 * s + 8 * g) * 2;
+                    const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
+                    const b8v kh = ld_b8(bb + B_KH * ARR + off), kl = ld_b8(bb + B_KL * ARR + off);
+                    sc = mfma32(rh, kh, sc);                  // A[row a][col b]: lane col b = x, rows a = 4g+q
+                    sc = mfma32(rh, kl, sc);
+                    sc = mfma32(rl, kh, sc);
+                }
+                const float4 cfa = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 16 * g);
+                const float4 cfb = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 64 + 16 * g);
+                const float cf[4] = {cfa.x + cfb.x, cfa.y + cfb.y, cfa.z + cfb.z, cfa.w + cfb.w};
+                float scm[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 4 * g + q;                  // query token a; key token b = x
+                    scm[q] = x < o ? sc[q] : (x == o ? cf[q] : 0.f);
+                }
+                uint2 th, tl;
+                split4(scm, th, tl);
+                tile_store(XS_OFF + wv * 1024, th, tl);
+                publish(TAG_SC + wv, grp + 1);
             }
             // stage-entry forward state: read back what this wave requested a stage ago, then request the next one.
             // The DMA is invisible to the compiler's s_waitcnt bookkeeping: wait for it here.  It was issued a whole stage ago; the
@@ -795,10 +839,10 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 }
             }
             {
-                if (wv < SBLK) {   // this wave's score tile of the stage: block wv
+                if (!GONCE && wv < SBLK) {   // (split kernels: no row waves in this workgroup) this wave's score tile of the stage: block wv
                     const char* const bb = buf + wv * BBLK_BYTES;
                     f4v sc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+    #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const int off = x * RSB + (32 * s + 8 * g) * 2;
                         const b8v rh = ld_b8(bb + B_RH * ARR + off), rl = ld_b8(bb + B_RL * ARR + off);
@@ -811,7 +855,7 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                     const float4 cfb = *reinterpret_cast<const float4*>(bb + BOFF_COEF + 64 + 16 * g);
                     const float cf[4] = {cfa.x + cfb.x, cfa.y + cfb.y, cfa.z + cfb.z, cfa.w + cfb.w};
                     float scm[4];
-#pragma unroll
+    #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int o = 4 * g + q;                  // query token a; key token b = x
                         scm[q] = x < o ? sc[q] : (x == o ? cf[q] : 0.f);
