@@ -366,8 +366,9 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
         if (ngrp > 0) {
             load_group(ngrp - 1);
             take_group();
-            if (ngrp > 1) load_group(ngrp - 2);
+            if (GONCE && ngrp > 1) load_group(ngrp - 2);
             prep_group(ngrp - 1);
+            if (!GONCE && ngrp > 1) load_group(ngrp - 2);
         }
         __syncthreads();
         for (int grp = ngrp - 1; grp >= 0; --grp) {
@@ -378,10 +379,14 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             WKV6_T(ts1);
 #ifndef WKV6_ABL_NOPROD                                            // timing-only ablation: the stage images are prepared once
             if (grp > 0) {
-                take_group();                                      // stage s-1's inputs (requested a whole stage ago)
-                if (grp > 1) load_group(grp - 2);                  // the next request first: it flies during the whole preparation
+                // GONCE kernels (the consuming roles are light: a stage waits for the producers): the next request goes out BEFORE
+                // the preparation and flies during all of it.  Split kernels (this workgroup's four consuming waves are the heavier
+                // side): after it, as ever -- the early request costs them 5-8 %.
+                take_group();                                      // stage s-1's inputs
+                if (GONCE && grp > 1) load_group(grp - 2);
                 WKV6_T(ts2);
                 prep_group(grp - 1);
+                if (!GONCE && grp > 1) load_group(grp - 2);
             }
 #endif
             WKV6_T(ts3);
