@@ -334,10 +334,7 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
     // themselves (and the LDS executes one wave's operations in order) without a full memory barrier, which would stop it from
     // keeping the stage's many independent operand reads in flight around them.
     auto publish = [&](int idx, int tag) { if (lane == 0) *xflag_at(idx) = tag; };   // after this wave's (volatile) tile store
-    auto await = [&](int idx, int tag) {
-        while (__builtin_amdgcn_readfirstlane(*xflag_at(idx)) != tag) __builtin_amdgcn_s_sleep(1);
-    };
-    // two / four adjacent tags with one LDS round trip (a poll costs an LDS latency plus a drain of the wave's LDS queue)
+    // readers poll two / four adjacent tags with one LDS round trip (a poll costs an LDS latency plus a drain of the wave's LDS queue)
     typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
     auto await2 = [&](int idx, int tag) {
         for (;;) {
@@ -593,7 +590,7 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 // vg_x = dA[x][x] = gy_x . v_x: the producers' two half sums
                 const float vg = *reinterpret_cast<const float*>(bb + BOFF_VG + x * 4) + *reinterpret_cast<const float*>(bb + BOFF_VG + 64 + x * 4);
                 vgs[blk] = vg;
-                await2(TAG_DA + 2 * blk, grp + 1);
+                if (blk == SBLK - 1) await4(TAG_DA, grp + 1);     // all four dA tiles of the stage with one poll
                 const uint4 fab = tile_load(XT_OFF + (2 * blk) * 1024), fba = tile_load(XT_OFF + (2 * blk + 1) * 1024);
                 const s4v dab_hi = __builtin_bit_cast(s4v, make_uint2(fab.x, fab.y)), dab_lo = __builtin_bit_cast(s4v, make_uint2(fab.z, fab.w));
                 const s4v dba_hi = __builtin_bit_cast(s4v, make_uint2(fba.x, fba.y)), dba_lo = __builtin_bit_cast(s4v, make_uint2(fba.z, fba.w));
@@ -874,7 +871,7 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 for (int blk = 0; blk < SBLK; ++blk) gyT_w[blk] = tr_read(buf + blk * BBLK_BYTES + B_GY * ARR + troff + 32 * wv);   // gy[4g+e][16wv + x]
 #pragma unroll
                 for (int blk = 0; blk < SBLK; ++blk) {
-                    await(TAG_SC + blk, grp + 1);
+                    if (blk == 0) await2(TAG_SC, grp + 1);        // both score tiles with one poll
                     const uint4 f = tile_load(XS_OFF + blk * 1024);
                     sc_hi[blk] = __builtin_bit_cast(s4v, make_uint2(f.x, f.y));
                     sc_lo[blk] = __builtin_bit_cast(s4v, make_uint2(f.z, f.w));
