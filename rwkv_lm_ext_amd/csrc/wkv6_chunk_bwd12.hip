@@ -17,15 +17,20 @@
 // state-only variant, launch_chunk_state_pass) dumps the state at the entry of every 32-token stage (fp32) into
 // the workspace; this kernel walks the stages backwards and rebuilds the second block state of a stage in registers.
 //
-// One 768-thread workgroup (12 wave64) per (batch, head), one barrier per stage:
-//   * "row" waves 0..3 own key rows [16w,16w+16): forward states and G with lane = key row; they produce gr, gk, gw, gu;
-//   * "column" waves 4..7 own value columns [16w,16w+16): G with lane = value column; they produce the scores, gv, gs.
-//     G is kept in both orientations because gk contracts it over j and gv over i;
-//     The tiles all four waves of a role need alike -- dA in both orientations (row waves), the masked scores (column waves) -- are
-//     computed once per workgroup and handed over as MFMA fragments through LDS, each behind a tag its readers poll (XT_OFF below);
-//   * four dedicated producer waves (one per SIMD; wave = block x channel half, lane = 4 channels x 2 tokens) prepare
-//     stage s-1 into the other LDS buffer and issue the global loads of stage s-2 while stage s is consumed
-//     (three waves per SIMD, <= 168 VGPRs).
+// One 768-thread workgroup (12 wave64) per (batch, head), one barrier per stage, three roles with one wave of each per SIMD (<= 168 VGPRs):
+//   * "row" waves 0..3 own key rows [16w,16w+16): forward states with lane = key row; they produce gr, gk, gw, gu;
+//   * "column" waves 4..7 own value columns [16w,16w+16) and the adjoint state G (lane = value column); they produce gv, gs, run the
+//     stage's G recurrence first thing and publish the operand (E16m8 (.) G) hi | lo through LDS for the row waves' gk (GOP_OFF below),
+//     and they copy v, gy of the stage being prepared from global memory into its image;
+//   * four producer waves (wave = block x channel half, lane = 4 channels x 2 tokens) prepare the r / k / decay side of stage s-1 into
+//     the other LDS buffer while stage s is consumed, having requested stage s-2's inputs before they start;
+//   * tiles that every wave of a role needs alike -- dA in both orientations, the masked scores -- are made once per workgroup (row
+//     waves 2, 3 and 0, 1) and handed over as MFMA fragments; the waves of a workgroup are not synchronised inside a stage, so every
+//     hand-over carries a tag (stage index + 1) its readers poll (XT_OFF, xflag below).
+// Which role does what follows the per-phase stamps (profiles/r03_stage_level_backward.txt): a stage takes the sum of the issue
+// cycles of the three waves of a SIMD, and the role with the least slack sets the pace.
+// Where a (batch, head) pair is split over two workgroups (ScanArgs::split: few pairs, many CUs) row and column roles cannot share
+// LDS: those kernels (GONCE = false) keep G in both orientations, the producers copy v / gy, and the column waves make the score tiles.
 #include "wkv6_chunk.h"
 
 namespace wkv6 {
