@@ -379,7 +379,6 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
             asm volatile("" :: "v"(nr[0].x), "v"(nk[0].x), "v"(nr[1].x), "v"(nk[1].x));      // wait for the loads here
 #endif
             WKV6_T(ts1);
-#ifndef WKV6_ABL_NOPROD                                            // timing-only ablation: the stage images are prepared once
             if (grp > 0) {
                 // GONCE kernels (the consuming roles are light: a stage waits for the producers): the next request goes out BEFORE
                 // the preparation and flies during all of it.  Split kernels (this workgroup's four consuming waves are the heavier
@@ -390,7 +389,6 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
                 prep_group(grp - 1);
                 if (!GONCE && grp > 1) load_group(grp - 2);
             }
-#endif
             WKV6_T(ts3);
             __syncthreads();
             WKV6_T(ts4);
@@ -448,9 +446,6 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
 
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
-#ifdef WKV6_ABL_NOROW                                              // timing-only ablation: row waves only keep the barrier count
-            if (grp != ngrp - 1) { __syncthreads(); continue; }
-#endif
             WKV6_T(ts0);
             // first of all, so that it is there long before the others ask for it:
             if (wv >= 2) {   // this wave's dA tiles of the stage: block wv - 2, both orientations (tile 2 blk: dA[a][b], lane col b; 2 blk + 1:
@@ -790,9 +785,6 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
         }
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
-#ifdef WKV6_ABL_NOCOL                                              // timing-only ablation: column waves only keep the barrier count
-            if (grp != ngrp - 1) { __syncthreads(); continue; }
-#endif
             WKV6_T(ts0);
             if (GONCE && grp > 0) col_load(grp - 1);
             const char* const buf = smem + (grp & 1) * BUF_BYTES;
