@@ -273,8 +273,10 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
         // (a null y -- the fused-epilogue forward of an inference call -- gets a zero-sized resource: its stores are dropped)
         const rsrc_t rs_y = make_rsrc(a.y ? gy_ : nullptr, (!STATE_ONLY && a.y && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
-        const unsigned ckt = (unsigned)a.ckpt_tok;                               // 32 (12-wave backward) or 64 (two-level backward)
-        const unsigned nst = ((unsigned)a.T + ckt - 1) / ckt;                    // checkpoint slots of this (batch, head): 16 KB each
+        // checkpoint spacing: 32 or 64 tokens, a power of two -- shifts and masks below, not the 25-instruction scalar division
+        // sequences a run-time divisor costs the consumers in every block (round 4: that was the forward's +8 % of round 3)
+        const unsigned ckt = (unsigned)a.ckpt_tok, cksh = (unsigned)__builtin_ctz(ckt | 1024u);
+        const unsigned nst = ((unsigned)a.T + ckt - 1) >> cksh;                  // checkpoint slots of this (batch, head): 16 KB each
         // (two-level scan: this batch row is segment b % S of sequence b / S; the S segments' slots are consecutive, which is the
         // whole sequence's ordinary checkpoint layout)
         const int segs = a.ckpt_segs > 1 ? a.ckpt_segs : 1;
@@ -346,8 +348,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 #pragma unroll unroll_by
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
-                if (a.ckpt && (unsigned)(blk * BLK) % ckt == 0) {   // state every ckpt_tok tokens, for the backward kernel (slots past T: dropped)
-                    const unsigned st = (unsigned)(grp * GRP + blk * BLK) / ckt;
+                if (a.ckpt && ((unsigned)(blk * BLK) & (ckt - 1)) == 0) {   // state every ckpt_tok tokens, for the backward kernel (slots past T: dropped)
+                    const unsigned st = (unsigned)(grp * GRP + blk * BLK) >> cksh;
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {   // streamed: written once, read once by the backward
                         typedef unsigned v4u __attribute__((ext_vector_type(4)));

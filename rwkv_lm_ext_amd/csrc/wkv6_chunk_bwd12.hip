@@ -422,9 +422,6 @@ __device__ __forceinline__ void chunk_bwd12_body(const ScanArgs& a, const unsign
         const unsigned qbase = __builtin_amdgcn_readfirstlane(
             (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)qreg));   // LDS byte address, wave-uniform
         auto request_ckpt = [&](int stg) {
-#ifdef WKV6_ABL_CKHOT                                              // timing-only ablation: always the same (cache-resident) checkpoint
-            stg = 0;
-#endif
             const float* const ck = a.ckpt + ((long)(b * a.H + h) * nstmax + stg) * (HEAD * HEAD);
             const int fm = lane & 3, fgl = (lane >> 2) & 1, fp = (lane >> 3) & 3, fgh = lane >> 5;   // this lane as a fetch lane
             const int i0 = 16 * wv + 4 * fm, gq = 2 * fgh + fgl;

@@ -8,49 +8,66 @@ state and hands the final state on (RUN_CUDA_RWKV6_STATE of the 'infctx' flavour
 import torch
 
 
+from dataclasses import dataclass
+
+
+@dataclass
 class TimeMixState:
-    def __init__(self, shift_state, wkv_state):
-        self.shift_state = shift_state
-        self.wkv_state = wkv_state
+    """What a time-mix layer carries to the next chunk: the last token (for the token shift) and the WKV state [B, H, N, N]."""
+    shift_state: torch.Tensor
+    wkv_state: torch.Tensor
 
 
+@dataclass
 class ChannelMixState:
-    def __init__(self, shift_state):
-        self.shift_state = shift_state
+    """What a channel-mix layer carries: the last token of the chunk."""
+    shift_state: torch.Tensor
 
 
+@dataclass
 class BlockState:
-    def __init__(self, time_mix_state, channel_mix_state):
-        self.time_mix_state = time_mix_state
-        self.channel_mix_state = channel_mix_state
+    time_mix_state: TimeMixState
+    channel_mix_state: ChannelMixState
+
+
+_TMIX, _CMIX = 0, 1          # slot of each sub-layer in shift_states[layer]
 
 
 class BlockStateList:
+    """All layers' carried state in two tensors: `wkv_states` [L, B, H, N, N] (always bf16: the kernels' state dtype) and
+    `shift_states` [L, 2, B, C] (activation dtype).  Indexing with a layer number gives views, assignment copies into them.
+    Same constructor, factories, attribute names and indexing protocol as the reference's container (src/infctx_module.py:20-50),
+    because training scripts build and index it directly."""
+
     def __init__(self, shift_states, wkv_states):
-        self.wkv_states = wkv_states
-        self.shift_states = shift_states
+        self.shift_states, self.wkv_states = shift_states, wkv_states
+
+    @classmethod
+    def _allocate(cls, alloc, n_layer, B, C, H, device, dtype):
+        head = C // H
+        return cls(alloc((n_layer, 2, B, C), device=device, dtype=dtype),
+                   alloc((n_layer, B, H, head, head), device=device, dtype=torch.bfloat16))
 
     @staticmethod
     def empty(N, B, C, H, device, dtype):
-        wkv_states = torch.empty((N, B, H, C // H, C // H), device=device, dtype=torch.bfloat16)
-        shift_states = torch.empty((N, 2, B, C), device=device, dtype=dtype)
-        return BlockStateList(shift_states, wkv_states)
+        return BlockStateList._allocate(torch.empty, N, B, C, H, device, dtype)
 
     @staticmethod
     def create(N, B, C, H, device, dtype):
-        result = BlockStateList.empty(N, B, C, H, device, dtype)
-        result.wkv_states[:] = 0
-        result.shift_states[:] = 0
-        return result
+        return BlockStateList._allocate(torch.zeros, N, B, C, H, device, dtype)
+
+    def __len__(self):
+        return self.wkv_states.shape[0]
 
     def __getitem__(self, layer):
-        return BlockState(TimeMixState(self.shift_states[layer, 0], self.wkv_states[layer]),
-                          ChannelMixState(self.shift_states[layer, 1]))
+        shift = self.shift_states[layer]
+        return BlockState(TimeMixState(shift[_TMIX], self.wkv_states[layer]), ChannelMixState(shift[_CMIX]))
 
     def __setitem__(self, layer, state):
-        self.shift_states[layer, 0] = state.time_mix_state.shift_state
-        self.wkv_states[layer] = state.time_mix_state.wkv_state
-        self.shift_states[layer, 1] = state.channel_mix_state.shift_state
+        tm, cm = state.time_mix_state, state.channel_mix_state
+        self.wkv_states[layer].copy_(tm.wkv_state)
+        self.shift_states[layer, _TMIX].copy_(tm.shift_state)
+        self.shift_states[layer, _CMIX].copy_(cm.shift_state)
 
 
 def _default_wkv_state(B, T, C, H, r, k, v, w, u, s):

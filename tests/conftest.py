@@ -31,42 +31,7 @@ def load_golden_mid(name):
     return out
 
 
-def max_norm_err(a, b, floor=1e-3):
-    """max|a-b| / max(max|b|, floor)  -- the metric every fp32 tolerance in this suite is stated in.
-    `floor` keeps an all-zero expectation (gw at T <= 2) from turning fp32 cancellation noise into inf;
-    test tensors are O(1)."""
-    a = np.asarray(a, np.float64)
-    b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
-
-
-def bf16_round(x):
-    """Round-to-nearest-even to bfloat16, returned as float32 (numpy)."""
-    x = np.ascontiguousarray(x, np.float32)
-    u = x.view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
-    return r.astype(np.uint32).view(np.float32)
-
-
-def bf16_report(out, ref, floor=1e-3):
-    """Compare a bf16 kernel output (as float32) with the fp64/fp32 oracle result.
-
-    Returns (rel_rms, frac_off, max_ulps): error against RNE_bf16(oracle), normalised by the rms of the
-    oracle; fraction of the significant elements (>= 1 % of max|ref|) that are not the correctly rounded value; largest deviation in bf16 ulps
-    of max(|ref|, 1e-2*max|ref|).
-    """
-    out = np.asarray(out, np.float64)
-    ref = np.asarray(ref, np.float64)
-    want = bf16_round(ref.astype(np.float32)).astype(np.float64)
-    d = out - want
-    rms = max(np.sqrt(np.mean(ref ** 2)), floor)
-    rel_rms = float(np.sqrt(np.mean(d ** 2)) / rms)
-    floor = max(1e-2 * np.abs(ref).max(), floor)
-    big = np.abs(ref) >= floor            # elements below 1 % of the tensor scale sit in fp32 noise
-    frac_off = float(np.mean(d[big] != 0)) if big.any() else 0.0
-    ulp = np.maximum(np.abs(ref), floor) * 2.0 ** -7
-    max_ulps = float((np.abs(d) / ulp).max())
-    return rel_rms, frac_off, max_ulps
+from oracle.contract import max_norm_err, bf16_round, bf16_report      # noqa: E402,F401  (the contract lives beside the oracle)
 
 
 @pytest.fixture(scope="session")

@@ -13,19 +13,4 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $ROOT/$OUT/pmc$i -- python3 $ROOT/tools/run_bwd.py $N > $ROOT/$OUT/pmc$i.log 2>&1 || echo "pmc group $i failed: $grp"
 done
 cd $ROOT
-python3 tools/pmc_agg.py $OUT; exit 0
-python3 - <<PY
-import csv, glob, collections
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("$OUT/pmc*/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"]
-        if "chunk" not in k: continue
-        k = k.split("(")[0].replace("void wkv6::(anonymous namespace)::", "")
-        acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-for k, d in acc.items():
-    print(k)
-    for c, v in sorted(d.items()):
-        v = sorted(v)[len(v) // 4:]     # drop the self-test / warm-up quartile
-        print(f"   {c:28s} {sum(v) / len(v):16.1f}   (n={len(v)})")
-PY
+python3 tools/pmc_agg.py $OUT
