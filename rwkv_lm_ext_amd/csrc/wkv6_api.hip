@@ -104,6 +104,31 @@ __global__ void length_order_kernel(const int* __restrict__ lens, int* __restric
 
 int to_rc(hipError_t e) { return e == hipSuccess ? WKV6_OK : (int)e; }
 
+// What a checkpoint buffer holds.  Spacing and layout of the checkpoints follow from switches that are read per call (WKV6_BWD,
+// WKV6_SPLIT: chunk_ckpt_plan); a backward that is told "the forward filled this buffer" (WKV6_CKPT_VALID) must not read a
+// 32-token forward-order image as a 64-token row-order one because a switch changed in between.  Every forward that writes
+// checkpoints notes (buffer, spacing, layout) here; a CKPT_VALID backward whose plan differs from the note rebuilds the
+// checkpoints with its own state pass instead of trusting them.  A buffer without a note is trusted (as before).
+struct CkptNote { const void* ptr; int tok, fmt; };
+std::mutex g_ckpt_mu;
+CkptNote g_ckpt_notes[128] = {};
+unsigned g_ckpt_next = 0;
+void ckpt_note(const void* ptr, const ScanArgs& a)
+{
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lk(g_ckpt_mu);
+    for (CkptNote& n : g_ckpt_notes)
+        if (n.ptr == ptr) { n.tok = a.ckpt_tok; n.fmt = a.ckpt_fmt; return; }
+    g_ckpt_notes[g_ckpt_next++ % 128] = CkptNote{ptr, a.ckpt_tok, a.ckpt_fmt};
+}
+bool ckpt_matches(const void* ptr, const ScanArgs& a)
+{
+    std::lock_guard<std::mutex> lk(g_ckpt_mu);
+    for (const CkptNote& n : g_ckpt_notes)
+        if (n.ptr == ptr) return n.tok == a.ckpt_tok && n.fmt == a.ckpt_fmt;
+    return true;
+}
+
 // ---- forward over few, long sequences (inference prefill: B*H << CUs): two-level scan over T.  The sequence is cut into S
 // segments that run as S times as many workgroups:
 //   1. state pass per segment from a zero state: A_seg = the segment's own contribution to the state, and the per-channel sum
@@ -192,7 +217,8 @@ hipError_t run_bwd(ScanArgs& a, unsigned flags, float* scratch, hipStream_t st)
         return launch_scan_bwd(a, flags & WKV6_IO_F32, st);
     }
     a.ckpt = scratch;
-    a.ckpt_valid = (flags & WKV6_CKPT_VALID) ? 1 : 0;
+    a.ckpt_valid = ((flags & WKV6_CKPT_VALID) && ckpt_matches(scratch, a)) ? 1 : 0;
+    if (!a.ckpt_valid) ckpt_note(scratch, a);      // the state pass of this call fills it
     return launch_chunk_bwd(a, st);
 }
 
@@ -205,13 +231,15 @@ ScanArgs base_args(int B, int T, int C, int H, const void* r, const void* k, con
     a.wkind = (flags & WKV6_W_RAW) ? 1 : 0;
     a.part_f32 = (flags & WKV6_PARTIALS_F32) ? 1 : 0;
     a.use_u = 1;
-    a.ckpt_tok = chunk_ckpt_tok(B * H);
+    const CkptPlan plan = chunk_ckpt_plan(B * H);
+    a.ckpt_tok = plan.tok;
+    a.ckpt_fmt = plan.fmt;
     return a;
 }
 
 }  // namespace
 
-#if defined(WKV6_STAMP) || defined(WKV6_CLOCK)
+#if defined(WKV6_STAMP) || defined(WKV6_CLOCK) || defined(WKV6_DEBUG)
 namespace wkv6 { unsigned long long* g_stamp_buffer = nullptr; }
 extern "C" void wkv6_set_debug_buffer(void* p) { wkv6::g_stamp_buffer = reinterpret_cast<unsigned long long*>(p); }
 #endif
@@ -309,6 +337,7 @@ int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* 
     a.s_out = s_out;
     a.y = y;
     a.ckpt = reinterpret_cast<float*>(ckpt);
+    ckpt_note(ckpt, a);
     return to_rc(chunk_forward(a, (hipStream_t)stream));
 }
 
@@ -327,6 +356,7 @@ int wkv6_forward_gn_ex(int B, int T, int C, int H, const void* r, const void* k,
     a.s_out = s_out;
     a.y = y;
     a.ckpt = reinterpret_cast<float*>(ckpt);
+    ckpt_note(ckpt, a);
     a.gn_gate = gate; a.gn_gamma = gamma; a.gn_beta = beta; a.gn_eps = eps; a.gn_out = out; a.gn_stats = stats;
     return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
 }
@@ -368,6 +398,7 @@ int wkv6_forward_rev_ex(int B, int T, int C, int H, const void* r, const void* k
     if (flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN))        // exact scan kernels (fp32 I/O, or forced): same index maps, no checkpoints
         return to_rc(launch_scan_fwd(a, flags & WKV6_IO_F32, (hipStream_t)stream));
     a.ckpt = reinterpret_cast<float*>(ckpt);
+    ckpt_note(ckpt, a);
     return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
 }
 
@@ -412,9 +443,10 @@ static int pair_args(int B, int T, int C, int H, const void* u, const wkv6_seq_s
         a[i].rev_mask = q.rev_n ? q.rev_mask : 0u;
         if (bwd) {
             a[i].gy = q.gy; a[i].gr = q.gr; a[i].gk = q.gk; a[i].gv = q.gv; a[i].gw = q.gw; a[i].gu = q.gu;
-            a[i].ckpt_valid = 1;
+            a[i].ckpt_valid = ckpt_matches(q.ckpt, a[i]) ? 1 : 0;
         } else {
             a[i].y = q.y;
+            ckpt_note(q.ckpt, a[i]);
         }
     }
     return WKV6_OK;
@@ -431,6 +463,14 @@ int wkv6_backward_pair_ex(int B, int T, int C, int H, const void* u, const wkv6_
 {
     ScanArgs a[2];
     if (int rc = pair_args(B, T, C, H, u, s, flags, true, a)) return rc;
+    if (!a[0].ckpt_valid || !a[1].ckpt_valid) {       // checkpoints written under another plan: two self-contained backwards
+        for (int i = 0; i < 2; ++i) {
+            a[i].ckpt_valid = 0;
+            ckpt_note(a[i].ckpt, a[i]);
+            if (hipError_t e = launch_chunk_bwd(a[i], (hipStream_t)stream)) return (int)e;
+        }
+        return WKV6_OK;
+    }
     return to_rc(launch_chunk_bwd_pair(a[0], a[1], (hipStream_t)stream));
 }
 
@@ -460,9 +500,11 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
     a.lens = lens;
     a.zero_tail = 1;                          // y[t > L_b] = 0 (the reference leaves it uninitialised, Q2)
     a.ckpt = keep ? ws.scan[0] : nullptr;
+    ckpt_note(a.ckpt, a);
     if (hipError_t e = run_fwd(a, flags, st)) return (int)e;
     a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0;   // cuda/wkv6_bi_cuda.cu:71-111
     a.ckpt = keep ? ws.scan[1] : nullptr;
+    ckpt_note(a.ckpt, a);
     return to_rc(run_fwd(a, flags, st));
 }
 

@@ -6,7 +6,8 @@
 // wkv6_set_debug_buffer(); no stamp executes in the normal build.
 // -DWKV6_CLOCK: only one (s_memtime, s_memrealtime) pair around each wave's whole life, slots 6 / 7 of its record: the in-kernel
 // shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz with no per-phase stamp in the loop (tools/clock_probe.py).
-#if defined(WKV6_STAMP) || defined(WKV6_CLOCK)
+// -DWKV6_DEBUG: the LDS tag polls of the backward count their tries and trap with a record in the debug buffer instead of spinning forever.
+#if defined(WKV6_STAMP) || defined(WKV6_CLOCK) || defined(WKV6_DEBUG)
 #define WKV6_DEBUGBUF 1
 #define WKV6_CLK(c, r) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r) :: "memory")
 namespace wkv6 { extern unsigned long long* g_stamp_buffer; }

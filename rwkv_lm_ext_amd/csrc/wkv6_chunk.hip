@@ -39,6 +39,7 @@ namespace {
 using namespace chunk;
 
 constexpr int GRP_BYTES = NBLK * BLK_BYTES;
+constexpr int CKX_BYTES = 4 * 4096;         // checkpoint transposition buffers of the four consumers (CKPT_ROW_ORDER)
 
 // STATE_ONLY: no outputs, only the state recurrence (first half of the self-contained backward).
 // With a.ckpt the state is dumped every a.ckpt_tok tokens (fp32, register order:
@@ -53,7 +54,7 @@ constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false>
 __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2]
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2] | float [4 consumers][1024]
     const int tid = threadIdx.x, lane = tid & 63;
     // a.split (B*H <= half the CUs): two 6-wave workgroups per (batch, head) on two CUs, each with all four producers and two
     // of the four consumers (value columns [32 part, 32 part + 32)): hardware wave w plays consumer 2 part + w for w < 2 and
@@ -274,7 +275,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         // (a null y -- the fused-epilogue forward of an inference call -- gets a zero-sized resource: its stores are dropped)
         const rsrc_t rs_y = make_rsrc(a.y ? gy_ : nullptr, (!STATE_ONLY && a.y && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
         // checkpoint spacing: 32 or 64 tokens, a power of two -- shifts and masks below, not the 25-instruction scalar division
-        // sequences a run-time divisor costs the consumers in every block (round 4: that was the forward's +8 % of round 3)
+        // sequences a run-time divisor costs the consumers in every block (worth 0-0.5 %: profiles/r04_fwd_ab.txt)
         const unsigned ckt = (unsigned)a.ckpt_tok, cksh = (unsigned)__builtin_ctz(ckt | 1024u);
         const unsigned nst = ((unsigned)a.T + ckt - 1) >> cksh;                  // checkpoint slots of this (batch, head): 16 KB each
         // (two-level scan: this batch row is segment b % S of sequence b / S; the S segments' slots are consecutive, which is the
@@ -297,6 +298,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         uint2 gn_g[NBLK];
         unsigned gn_off[NBLK];
         char* const gn_stat = smem + 2 * GRP_BYTES;
+        char* const ckx = smem + 2 * GRP_BYTES + (GN ? 4096 : 0) + hwid * 4096;   // this consumer's checkpoint transposition buffer
         const unsigned gn_bytes = (GN && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
         const rsrc_t rs_gate = make_rsrc(GN ? reinterpret_cast<const bf16_t*>(a.gn_gate) + base : nullptr, gn_bytes);
         const rsrc_t rs_out = make_rsrc(GN ? reinterpret_cast<bf16_t*>(a.gn_out) + base : nullptr, gn_bytes);
@@ -350,11 +352,33 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
                 if (a.ckpt && ((unsigned)(blk * BLK) & (ckt - 1)) == 0) {   // state every ckpt_tok tokens, for the backward kernel (slots past T: dropped)
                     const unsigned st = (unsigned)(grp * GRP + blk * BLK) >> cksh;
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    if (a.ckpt_fmt == CKPT_ROW_ORDER) {
+                        // The backward's row waves want key row i on the lane and four consecutive value columns per register quad;
+                        // here a lane holds one value column j and four consecutive key rows per quad.  The 64 x 16 slice of this
+                        // wave goes through 4 KB of LDS: 16 scalar writes, 4 float4 reads, both conflict-free with the float index
+                        //     jl0 | jl1 | jl2^i0 | jl3^i1 | i3 | i2 | i0 | i1 | i4 | i5        (i = key row, jl = j - 16 wv)
+                        // (the 32 lanes of a write group differ in jl and i3, the 16 lanes of a float4 read group in i0..i3 with
+                        // jl3 = i2 ^ i3 ^ const: both land on distinct banks), then leaves as four coalesced 16-byte stores -- per
+                        // (row wave, column tile, g) 16 lanes cover 256 contiguous bytes of the backward's register image.
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {   // streamed: written once, read once by the backward
-                        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, St[it]), rs_ck,
-                                                               (int)(((st * 16u + wv * 4u + it) * 64u + lane) * 16u), 0, 2 /* slc: streaming */);
+                        for (int it = 0; it < 4; ++it)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)     // S[i = tile_ch(it) + 8g + q][jl = x]
+                                *reinterpret_cast<float*>(ckx + ((x ^ (q << 2)) + 16 * (g & 1) + 256 * (g >> 1) + 64 * (q & 1) + 128 * (q >> 1)
+                                                                 + 32 * (it & 1) + 512 * (it >> 1)) * 4) = St[it][q];
+#pragma unroll
+                        for (int wb = 0; wb < 4; ++wb) {    // lane (x, g) -> S[i = 16 wb + x][j = 16 wv + 4 (g >> 1) + 8 (g & 1) + 0..3]
+                            const v4u t = *reinterpret_cast<const v4u*>(ckx + (4 * ((g >> 1) ^ (x & 1)) + 8 * ((g & 1) ^ ((x >> 1) & 1)) + 16 * ((x >> 3) & 1)
+                                                                              + 32 * ((x >> 2) & 1) + 64 * (x & 1) + 128 * ((x >> 1) & 1) + 256 * wb) * 4);
+                            __builtin_amdgcn_raw_buffer_store_b128(t, rs_ck, (int)(st * 16384u + wb * 4096u
+                                + (((2 * (wv >> 1) + (g >> 1)) * 64 + 16 * (2 * (wv & 1) + (g & 1)) + x) * 16)), 0, 2 /* slc: streaming */);
+                        }
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < 4; ++it)   // streamed: written once, read once by the backward
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, St[it]), rs_ck,
+                                                                   (int)(((st * 16u + wv * 4u + it) * 64u + lane) * 16u), 0, 2 /* slc: streaming */);
                     }
                 }
                 // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
@@ -493,7 +517,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_pair_kernel(const ScanArgs a0, 
 
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (size_t)GRP_BYTES + (GN ? 4096 : 0);
+    constexpr size_t lds = 2 * (size_t)GRP_BYTES + (GN ? 4096 : 0) + CKX_BYTES;
     static LdsAttrOnce attr;                   // per instantiation and device
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), lds)) return e;
     if (a.split) hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), dim3(2 * a.B * a.H), dim3(384), lds, st, a);
@@ -539,7 +563,7 @@ hipError_t launch_chunk_fwd_pair(const ScanArgs& a0_, const ScanArgs& a1_, hipSt
     }
     ScanArgs a0 = a0_, a1 = a1_;
     a0.split = a1.split = 0;
-    constexpr size_t lds = 2 * (size_t)GRP_BYTES;
+    constexpr size_t lds = 2 * (size_t)GRP_BYTES + CKX_BYTES;
     static LdsAttrOnce attr_raw, attr_ew;
     if (a0.wkind == 1) {
         if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_fwd_pair_kernel<true>), lds)) return e;
@@ -562,7 +586,7 @@ hipError_t launch_chunk_state_pass(const ScanArgs& a_, hipStream_t st)
 
 size_t chunk_ckpt_floats(int B, int T, int H)
 {
-    const int ckt = chunk_ckpt_tok(B * H);
+    const int ckt = chunk_ckpt_plan(B * H).tok;
     return (size_t)B * H * ((T + ckt - 1) / ckt) * HEAD * HEAD;
 }
 

@@ -1041,16 +1041,21 @@ int want_split(int BH)
     return 2 * BH <= cu_count();
 }
 
-// Which chunked backward serves a call, hence how far apart the forward's checkpoints are.  Default: this 12-wave staged kernel
-// (checkpoints every 32 tokens).  WKV6_BWD=64 selects the two-level 16-wave kernel (wkv6_chunk_bwd64.hip, checkpoints every 64
-// tokens: half the checkpoint memory and traffic, forward 10 % faster, backward 21 % slower at config 2 -- profiles/r03_bwd64_*),
-// except where two workgroups share a (batch, head) pair (ScanArgs::split), which only this kernel can do.
-int chunk_ckpt_tok(int BH)
+// Which chunked backward serves a call, hence how far apart the forward's checkpoints are and how one is laid out (wkv6_scan.h).
+// Default: wkv6_chunk_bwd12k.hip (64-token checkpoints in row-wave order); where two workgroups share a (batch, head) pair
+// (ScanArgs::split) this file's kernel with 32-token checkpoints, which is the only one that can.  A/B switches, read per call (a
+// backward that is told its checkpoints are valid checks what the forward recorded for that buffer: wkv6_api.hip, ckpt_registry):
+// WKV6_BWD=32 -- this file's kernel for every launch (the round-3 default); WKV6_BWD=64 -- the two-level 16-wave experiment
+// wkv6_chunk_bwd64.hip (64-token checkpoints in forward order; profiles/r03_bwd64_*).
+CkptPlan chunk_ckpt_plan(int BH)
 {
+    const bool split = want_split(BH) != 0;
     if (const char* e = getenv("WKV6_BWD")) {
-        if (atoi(e) == 64) return want_split(BH) ? STG : 64;
+        const int v = atoi(e);
+        if (v == 64) return split ? CkptPlan{STG, CKPT_FWD_ORDER} : CkptPlan{64, CKPT_FWD_ORDER};
+        if (v == 32 || v == 12) return CkptPlan{STG, CKPT_FWD_ORDER};
     }
-    return STG;
+    return split ? CkptPlan{STG, CKPT_FWD_ORDER} : CkptPlan{64, CKPT_ROW_ORDER};
 }
 
 hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)
@@ -1058,12 +1063,14 @@ hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)
     ScanArgs a = a_;
     a.split = a.ckpt_tok == STG ? want_split(a.B * a.H) : 0;
     if (a.ckpt_tok != STG && a.ckpt_tok != 64) return hipErrorInvalidValue;
+    if (a.ckpt_fmt == CKPT_ROW_ORDER && a.ckpt_tok != 64) return hipErrorInvalidValue;
     if (a.wkind != 1 && ((long)a.T + 64) * a.C >= (1L << 30)) return hipErrorInvalidValue;   // 32-bit byte offsets of the fp32 decay input
     if (!a.ckpt_valid) {                   // self-contained backward: state pass first (same inputs, no outputs)
         ScanArgs sp = a;
         sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
         if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
     }
+    if (a.ckpt_fmt == CKPT_ROW_ORDER) return launch_chunk_bwd12k(a, st);
     if (a.ckpt_tok == 64) return launch_chunk_bwd64(a, st);
 #ifdef WKV6_DEBUGBUF
     ScanArgs b = a;
@@ -1083,13 +1090,18 @@ hipError_t launch_chunk_bwd_pair(const ScanArgs& a0_, const ScanArgs& a1_, hipSt
         return !a.accumulate && !a.zero_tail && !a.g_f32[0] && !a.g_f32[1] && !a.g_f32[2] && !a.g_f32[3] && a.ckpt && a.ckpt_valid;
     };
     if (!plain(a0_) || !plain(a1_)) return hipErrorNotSupported;
-    if (a0_.ckpt_tok != STG || a1_.ckpt_tok != STG || want_split(a0_.B * a0_.H)) {
+    const bool rowfmt = a0_.ckpt_fmt == CKPT_ROW_ORDER && a1_.ckpt_fmt == CKPT_ROW_ORDER && a0_.ckpt_tok == 64 && a1_.ckpt_tok == 64;
+    if ((!rowfmt && (a0_.ckpt_tok != STG || a1_.ckpt_tok != STG || a0_.ckpt_fmt != a1_.ckpt_fmt)) || want_split(a0_.B * a0_.H)) {
         if (hipError_t e = launch_chunk_bwd(a0_, st)) return e;
         return launch_chunk_bwd(a1_, st);
     }
     if (a0_.wkind != 1 && ((long)a0_.T + 64) * a0_.C >= (1L << 30)) return hipErrorInvalidValue;
     ScanArgs a0 = a0_, a1 = a1_;
     a0.split = a1.split = 0;
+#ifdef WKV6_DEBUGBUF
+    a0.aux = a1.aux = reinterpret_cast<float*>(g_stamp_buffer);
+#endif
+    if (rowfmt) return launch_chunk_bwd12k_pair(a0, a1, st);
     constexpr size_t lds = BWD12_LDS;
     static LdsAttrOnce attr_raw, attr_ew;
     if (a0.wkind == 1) {

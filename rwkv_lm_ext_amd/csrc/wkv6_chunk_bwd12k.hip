@@ -1,0 +1,964 @@
+// Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O): 12-wave staged kernel over 64-token checkpoints (the default backward).
+// Companion of wkv6_chunk.hip; wkv6_chunk_bwd12.hip is its 32-token-checkpoint sibling for launches with two workgroups per (batch, head).
+//
+// Per 16-token block (a = query token, b = key token, c_a exclusive cumulative log decay, S = forward state at
+// block entry, G = dL/d(state after the block)), with Rhat_a = r_a e^{c_a - c_8}, Khat_b = k_b e^{c_8 - c_{b+1}},
+// fR_a = e^{c_a - c_8}, fK_b = e^{c_8 - c_{b+1}}, E8 = e^{c_8}, E16 = e^{c_16}, E16m8 = e^{c_16 - c_8}:
+//   dA[a][b]  = gy_a . v_b                         (b < a),      vg_a = gy_a . v_a
+//   gv_b      = sum_{a>b} A[a][b] gy_a + (sum_i r_b u k_b) gy_b + sum_i Khat_b[i] (E16m8 (.) G)[i][:]
+//   dq_a      = fR_a (.) ( sum_{b<a} dA[a][b] Khat_b + (E8 (.) S) gy_a )        gr_a = dq_a + vg_a u (.) k_a
+//   dk_b      = fK_b (.) ( sum_{a>b} dA[a][b] Rhat_a + (E16m8 (.) G) v_b )      gk_b = dk_b + vg_b u (.) r_b
+//   G_entry   = E16 (.) G + E8 (.) sum_a Rhat_a gy_a^T
+//   gw_t      = lw_t (.) ( sum_{s>t} (r_s (.) dq_s - k_s (.) dk_s) - k_t (.) dk_t )   (suffix sum over the whole
+//               sequence; identity of fla/ops/rwkv6/recurrent_fuse.py:394-396, same as the scan kernels)
+//   gu       += vg_a r_a (.) k_a
+// i.e. the adjoint of cuda/wkv6_cuda.cu:44-57 (reference backward: cuda/wkv6_cuda.cu:63-227), re-associated.
+//
+// The forward states are needed in reverse order.  The forward kernel (or, for a self-contained backward, its state-only variant,
+// launch_chunk_state_pass) dumps the state at every 64-token boundary (fp32, 4 B per token-channel) in the register order of this
+// kernel's row waves (CKPT_ROW_ORDER, wkv6_scan.h); this kernel walks 32-token stages backwards, takes the checkpoint of the
+// enclosing 64-token pair straight into registers (four coalesced 16-byte loads per lane, requested a stage's chain ahead) and
+// rebuilds what lies between: one block state inside every stage as before, and on the ODD stage of a pair the two block states
+// of the even stage in front of it.  That rebuild needs Khat, V and the block decays of stage s-1 while stage s is consumed, one
+// stage before the pipeline would otherwise have them: so the stage image is made in two parts,
+//   * the "K part" (Khat hi | lo, V, E16, E16m8: 8 KB per block) TWO stages ahead, into a ring of three slots,
+//   * the "R part" (Rhat hi | lo, gy, raw r, k, fR, lw, E8, r.u.k, gy.v: 22 KB per block) one stage ahead, double-buffered,
+// with the decay prefix of a stage carried in the producers' registers from its K part to its R part.  The ring takes exactly the
+// LDS the checkpoint queue of the 32-token scheme (wkv6_chunk_bwd12.hip, LDS-DMA) used to occupy: 160 KB in all.
+//
+// One 768-thread workgroup (12 wave64) per (batch, head), one barrier per stage, three roles with one wave of each per SIMD (<= 168 VGPRs):
+//   * "row" waves 0..3 own key rows [16w,16w+16): forward states with lane = key row; they produce gr, gk, gw, gu;
+//   * "column" waves 4..7 own value columns [16w,16w+16) and the adjoint state G (lane = value column); they produce gv, gs, run the
+//     stage's G recurrence first thing and publish the operand (E16m8 (.) G) hi | lo through LDS for the row waves' gk (GOP_OFF below),
+//     and they copy v (of stage s-2, K part) and gy (of stage s-1, R part) from global memory into the images;
+//   * four producer waves (wave = block x channel half, lane = 4 channels x 2 tokens) prepare the R part of stage s-1 and the K part of
+//     stage s-2 while stage s is consumed, having requested the inputs of the stages behind those before they start;
+//   * tiles that every wave of a role needs alike -- dA in both orientations, the masked scores -- are made once per workgroup (row
+//     waves 2, 3 and 0, 1) and handed over as MFMA fragments; the waves of a workgroup are not synchronised inside a stage, so every
+//     hand-over carries a tag (stage index + 1) its readers poll (XT_OFF, xflag below).
+// Launches that split a (batch, head) pair over two workgroups (ScanArgs::split) stay with wkv6_chunk_bwd12.hip and its 32-token
+// checkpoints: the row and column roles cannot share LDS there.
+#include "wkv6_chunk.h"
+
+namespace wkv6 {
+
+namespace {
+
+using namespace chunk;
+
+enum { R_RH = 0, R_RL, R_GY, R_R, R_K, NR_ARR };                       // R part, bf16 [16][RSB/2] each
+enum { K_KH = 0, K_KL, K_V, NK_ARR };                                  // K part
+constexpr int FRS = 72 * 4;                                            // bytes per fp32 token row (conflict-free float4 row reads)
+constexpr int ROFF_FR = NR_ARR * ARR;                                  // float [16][72]  fR_a = e^{c_a - c_8}
+// (no fK array: fK_b = e^{c_8 - c_{b+1}} = 1 / fR_{b+1}, with fR_16 = E16m8 -- the row waves read fR one token further and take the reciprocal)
+constexpr int ROFF_LW = ROFF_FR + BLK * FRS;                           // float [16][72]  lw_a e^{lw_a - max(lw_a, LW_MIN)}
+constexpr int ROFF_E8 = ROFF_LW + BLK * FRS;                           // float [64]
+constexpr int ROFF_COEF = ROFF_E8 + 256;                               // float [2][16]  per-half sum_i r u k
+constexpr int ROFF_VG = ROFF_COEF + 128;                               // float [2][16]  per-half gy_a . v_a
+constexpr int RBLK_BYTES = ROFF_VG + 128;
+constexpr int KOFF_E16 = NK_ARR * ARR;                                 // float [64]
+constexpr int KOFF_E16M8 = KOFF_E16 + 256;
+constexpr int KBLK_BYTES = KOFF_E16M8 + 256;
+constexpr int STG = 32, SBLK = STG / BLK;                             // tokens / blocks per stage
+constexpr int RBUF_BYTES = SBLK * RBLK_BYTES;                          // R part of one stage; two of them
+constexpr int KBUF_BYTES = SBLK * KBLK_BYTES;                          // K part of one stage; ring of three
+constexpr int KRING = 3;
+constexpr int KP_OFF = 2 * RBUF_BYTES;
+constexpr int CKT = 64;                                                // tokens between checkpoints
+// Tiles that every row wave (dA, both orientations, per block) and every column wave (masked scores per block) needs are computed
+// ONCE per workgroup and handed over as MFMA fragments: row waves 2 and 3 make the dA tiles of blocks 0 and 1 (both orientations), row
+// waves 0 and 1 the score tiles of blocks 0 and 1.  The waves of a role are not synchronised inside a stage, so each tile carries a tag
+// (stage index + 1) that its readers poll; the tags live in the unused padding of the first image rows.
+constexpr int XT_OFF = KP_OFF + KRING * KBUF_BYTES;                    // uint4 [4 tiles][64 lanes]  dA fragments: bf16x4 hi | bf16x4 lo
+constexpr int XS_OFF = XT_OFF + 4 * 1024;                              // uint4 [2 tiles][64 lanes]  score fragments
+constexpr int XFLAG_OFF = 128;                                         // int [6] in the padding of row 0 of the first array of buffer 0
+// G once per workgroup: the column waves own the adjoint state and publish the operand the row waves need, (E16m8 (.) G) split into
+// bf16 hi | lo, stored [value column j][key row i] with 144-byte rows, twice per stage (for block 1, then for block 0: one buffer, tags
+// GA "block 1's version is there" / GB "taken" / GC "block 0's version is there"); the row waves take it with transposing reads
+// instead of carrying, updating, scaling and splitting a second copy of G by rows.  The column waves run the stage's G recurrence
+// first thing, the row waves need its products last: nobody waits.
+constexpr int GRS = 144;                                               // bytes per row of the published operand
+constexpr int GOP_OFF = XS_OFF + 2 * 1024;                             // bf16 [2 (hi | lo)][64][GRS / 2]
+constexpr int TAG_DA = 0, TAG_SC = 4, TAG_GA = 8, TAG_GB = 12, TAG_GC = 16, N_TAGS = 20;   // tag slots (see xflag)
+constexpr int BWD12K_LDS = GOP_OFF + 2 * HEAD * GRS;
+static_assert(BWD12K_LDS <= 160 * 1024, "LDS budget");
+
+// One step of four independent in-row suffix sums: x[q] += x[q] of the lane `ctrl` names (lanes without a source keep their
+// value: DPP disables them).  Single v_add_f32_dpp instructions (the builtin gives v_mov_dpp + v_add).  A VALU write of a VGPR
+// must be 2 wait states ahead of a DPP read of it and nothing inside an asm string is padded by the compiler: the four
+// chains are interleaved so that they keep that distance among themselves, and each step opens with s_nop 1 for whatever
+// the compiler may have placed in front of it (a register copy, the subtraction that produced x).
+#define WKV6_DPP_ACC4(x, ctrl) asm("s_nop 1\n\t" \
+    "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf" \
+    : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
+
+// split a C-layout tile pair (8 floats) into the hi / lo bf16x8 fragments of one k-step
+__device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4], b8v& hi, b8v& lo)
+{
+    uint2 h0, l0, h1, l1;
+    split4(t0, h0, l0);
+    split4(t1, h1, l1);
+    hi = __builtin_bit_cast(b8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+
+// GEN = 0: gradients are plain bf16 stores (buffer stores, tokens past the end dropped by the hardware): no store-mode
+// branches at all.  GEN = 1: the first half of wkv6_bi (fp32 side buffers instead of the outputs, tail zeroing) -- stores only.
+// GEN = 2: the second half (adds the first half and rounds once); the addends are requested ahead of the work whose result
+// they meet.  One instantiation each: with the modes as run-time branches of one kernel hipcc merges the "a load may be
+// pending" state of the accumulate path into the other paths and drains the vector-memory queue -- s_waitcnt vmcnt(0) -- around
+// every store.
+// (The kernel proper is a device function of (arguments, workgroup slot) so that chunk_bwd12k_pair_kernel can run it on one of two
+// argument blocks: SURVEY.md row n2.)
+template <bool W_RAW, int GEN>
+__device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][RBLK_BYTES] | [3][SBLK][KBLK_BYTES] | tiles | G operand
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = (int)slot;
+    const bool rowrole = wid < 4, producer = wid >= 8;
+    const int wv = wid & 3;                                              // tile owned by a row / column wave
+    const int pb = wid & 1, half = (wid >> 1) & 1;                       // producer: block of the stage, channel half
+    const int b = a.order ? a.order[bh / a.H] : bh / a.H, h = bh % a.H;
+    const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
+                                                              // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
+    const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
+    const bf16_t* const gk_ = reinterpret_cast<const bf16_t*>(a.k) + base;
+    const bf16_t* const gv_ = reinterpret_cast<const bf16_t*>(a.v) + base;
+    const bf16_t* const ggy = reinterpret_cast<const bf16_t*>(a.gy) + base;
+    bf16_t* const ogr = reinterpret_cast<bf16_t*>(a.gr) + base;
+    bf16_t* const ogk = reinterpret_cast<bf16_t*>(a.gk) + base;
+    bf16_t* const ogv = reinterpret_cast<bf16_t*>(a.gv) + base;
+    bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw) + base;
+    int ntok = a.T;
+    if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
+    const RevMap tokmap = make_revmap(a, b, ntok);
+    // buffer resources over this row's first ntok tokens (wkv6_common.h): loads past the end return 0, stores are dropped
+    const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
+    const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);
+    // addend of a second-half store (GEN == 2), to be requested ahead of time: the first half's fp32 side buffer (or the output)
+    auto fetch_old = [&](int which, bf16_t* out, int p, unsigned bit, int ch, float (&old)[4]) {
+        if constexpr (GEN == 2) {
+            const int pc = p < ntok ? p : 0;                         // padding lanes still form a legal address
+            const unsigned idx = (unsigned)(tokmap(pc, bit) * a.C + ch);
+            float* const side = a.g_f32[which];
+            if (side) io4<float>::load(side + base + idx, old);
+            else io4<bf16_t>::load(out + idx, old);
+        }
+    };
+    // gradient store of scan position p, channels ch..ch+3: plain; or (wkv6_bi) first half into the fp32 side buffer, second half
+    // adds it and rounds once
+    auto emit = [&](int which, const rsrc_t& rs, bf16_t* out, int p, unsigned bit, int ch, float (&o)[4], const float (&old)[4]) {
+        const unsigned idx = (unsigned)(tokmap(p, bit) * a.C + ch);
+        if constexpr (GEN == 0) {
+            buf_store8(rs, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
+        } else if constexpr (GEN == 1) {
+            if (p >= ntok) return;
+            float* const side = a.g_f32[which];
+            if (side) io4<float>::store(side + base + idx, o);
+            else io4<bf16_t>::store(out + idx, o);
+        } else {
+            if (p >= ntok) return;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] += old[q];
+            io4<bf16_t>::store(out + idx, o);
+        }
+    };
+
+#ifdef WKV6_STAMP
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+#endif
+#ifdef WKV6_DEBUGBUF
+    unsigned long long clk0 = 0, rtc0 = 0, clk1 = 0, rtc1 = 0;
+    WKV6_CLK(clk0, rtc0);
+#endif
+    const int ngrp = (ntok + STG - 1) / STG;                      // stages
+    // images of stage s: R part in buffer s & 1, K part in ring slot s mod 3
+    auto rpart = [&](int stg, int blk) { return smem + (stg & 1) * RBUF_BYTES + blk * RBLK_BYTES; };
+    auto kpart = [&](int stg, int blk) { return smem + KP_OFF + (int)((unsigned)stg % (unsigned)KRING) * KBUF_BYTES + blk * KBLK_BYTES; };
+
+    // ---- producer role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block pb
+    const int c8i = lane & 7, tq = lane >> 3;
+    const int ch0 = 32 * half + 4 * c8i;
+    float uu[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + ch0, uu);
+
+    // register sets: n* = loads in flight (r of stage s-2; k, w of stage s-3), p* = the sets being worked on, c* = what a stage's K part
+    // hands to its R part one iteration later (raw k, exponents of fR, the gw multipliers, c_8)
+    uint2 pr[2], pk[2], pw[2];
+    float4 pe[2];
+    uint2 nr[2], nk[2], nw[2];
+    float4 ne[2];
+    uint2 ck_[2];
+    float cfr[2][4], clw[2][4], cc8[4] = {0.f, 0.f, 0.f, 0.f};
+    const rsrc_t rs_r = make_rsrc(gr_, nbytes), rs_k = make_rsrc(gk_, nbytes), rs_v = make_rsrc(gv_, nbytes), rs_g = make_rsrc(ggy, nbytes);
+    const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, nbytes)
+                              : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? (unsigned)(ntok - 1) * a.C * 4u + 256u : 0u);
+    auto load_r = [&](int stg) {       // tokens past the end load zeros
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int p = stg * STG + pb * BLK + 2 * tq + tt;
+            nr[tt] = buf_load8(rs_r, (unsigned)(tokmap(p, REV_R) * a.C + ch0) * 2u);
+        }
+    };
+    auto load_kw = [&](int stg) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int p = stg * STG + pb * BLK + 2 * tq + tt;
+            const unsigned ik = (unsigned)(tokmap(p, REV_K) * a.C + ch0), iw = (unsigned)(tokmap(p, REV_W) * a.C + ch0);
+            nk[tt] = buf_load8(rs_k, ik * 2u);
+            if constexpr (W_RAW) nw[tt] = buf_load8(rs_w, iw * 2u);
+            else ne[tt] = buf_load16f(rs_w, iw * 4u);
+        }
+    };
+    // the loaded set becomes the working set (register moves: the next loads may then overwrite n*)
+    auto take_r = [&]() {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) pr[tt] = nr[tt];
+        asm volatile("" : "+v"(pr[0].x), "+v"(pr[0].y), "+v"(pr[1].x), "+v"(pr[1].y));
+    };
+    auto take_kw = [&]() {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            pk[tt] = nk[tt];
+            if constexpr (W_RAW) pw[tt] = nw[tt]; else pe[tt] = ne[tt];
+        }
+        if constexpr (W_RAW)
+            asm volatile("" : "+v"(pk[0].x), "+v"(pk[0].y), "+v"(pk[1].x), "+v"(pk[1].y), "+v"(pw[0].x), "+v"(pw[0].y), "+v"(pw[1].x), "+v"(pw[1].y));
+        else
+            asm volatile("" : "+v"(pk[0].x), "+v"(pk[0].y), "+v"(pk[1].x), "+v"(pk[1].y),
+                              "+v"(pe[0].x), "+v"(pe[0].y), "+v"(pe[0].z), "+v"(pe[0].w), "+v"(pe[1].x), "+v"(pe[1].y), "+v"(pe[1].z), "+v"(pe[1].w));
+    };
+    // K part of stage `stg`: decays, prefix sums, Khat hi | lo, E16, E16m8; leaves ck_, cfr, clw, cc8 for prep_r of the same stage
+    auto prep_k = [&](int stg) {
+        char* const kb = kpart(stg, pb);
+        float k[2][4], cs[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const bool valid = stg * STG + pb * BLK + 2 * tq + tt < ntok;
+            k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
+            ck_[tt] = pk[tt];
+            float lw[4];
+            if constexpr (W_RAW) {
+                lw[0] = -exp2_fast(LOG2E * bf_lo(pw[tt].x)); lw[1] = -exp2_fast(LOG2E * bf_hi(pw[tt].x));
+                lw[2] = -exp2_fast(LOG2E * bf_lo(pw[tt].y)); lw[3] = -exp2_fast(LOG2E * bf_hi(pw[tt].y));
+            } else {
+                lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float l = valid ? fmaxf(lw[c] * LOG2E, LW_MIN2) : 0.f;   // the decay the block algebra uses, in log2 units
+                cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + l;
+                // gw multiplier: the true lw, times d_true / d_clamped where the clamp is active (the algebra yields the
+                // exact gradient of the clamped model, d_clamped * X; the true one is d_true * X)
+                clw[tt][c] = valid ? lw[c] : 0.f;
+            }
+            if (__builtin_amdgcn_ballot_w64(clw[tt][0] < LW_MIN || clw[tt][1] < LW_MIN || clw[tt][2] < LW_MIN || clw[tt][3] < LW_MIN)) {   // rare
+#pragma unroll
+                for (int c = 0; c < 4; ++c) clw[tt][c] *= exp2_fast(LOG2E * fminf(clw[tt][c] - LW_MIN, 0.f));
+            }
+        }
+        float pre[4], c8[4], c16[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // exclusive prefix over the 8 token-pair lanes by butterfly: after step k, tot = sum over the lane's aligned group of
+            // 2^k pairs, pfx = sum over the pairs before it inside the group
+            float tot = cs[1][c], a_, b_;
+            const float t = dpp_mov<DPP_ROR8>(tot);
+            float pfx = (tq & 1) ? t : 0.f;
+            tot += t;
+            rows16(tot, a_, b_);
+            pfx += (tq & 2) ? a_ : 0.f;
+            tot = a_ + b_;
+            halves32(tot, a_, b_);
+            pfx += (tq & 4) ? a_ : 0.f;
+            pre[c] = pfx;
+            c8[c] = a_;                                                  // tokens 0..7 = pairs 0..3 = the lower half's total
+            c16[c] = a_ + b_;                                            // whole block
+            cc8[c] = a_;
+        }
+        if (tq == 0) {
+            *reinterpret_cast<float4*>(kb + KOFF_E16 + ch0 * 4) =
+                make_float4(exp2_fast(c16[0]), exp2_fast(c16[1]), exp2_fast(c16[2]), exp2_fast(c16[3]));
+            *reinterpret_cast<float4*>(kb + KOFF_E16M8 + ch0 * 4) =
+                make_float4(exp2_fast(c16[0] - c8[0]), exp2_fast(c16[1] - c8[1]), exp2_fast(c16[2] - c8[2]), exp2_fast(c16[3] - c8[3]));
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float kh[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float cex = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
+                const float cin = pre[c] + cs[tt][c];
+                cfr[tt][c] = cex - c8[c];                                // fR = 2^this, formed with the R part
+                kh[c] = k[tt][c] * exp2_fast(c8[c] - cin);
+            }
+            char* const row = kb + (2 * tq + tt) * RSB + ch0 * 2;
+            uint2 hi, lo;
+            split4(kh, hi, lo);
+            *reinterpret_cast<uint2*>(row + K_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + K_KL * ARR) = lo;
+        }
+    };
+    // R part of stage `stg` (whose K part was the last one prepared): Rhat hi | lo, fR, lw, raw r / k, E8, r.u.k
+    auto prep_r = [&](int stg) {
+        char* const rb = rpart(stg, pb);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float r[4], k[4], rh[4], fr[4];
+            r[0] = bf_lo(pr[tt].x); r[1] = bf_hi(pr[tt].x); r[2] = bf_lo(pr[tt].y); r[3] = bf_hi(pr[tt].y);
+            k[0] = bf_lo(ck_[tt].x); k[1] = bf_hi(ck_[tt].x); k[2] = bf_lo(ck_[tt].y); k[3] = bf_hi(ck_[tt].y);
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part = fmaf(r[c] * uu[c], k[c], part);
+            part += dpp_mov<DPP_XOR1>(part);
+            part += dpp_mov<DPP_XOR2>(part);
+            part += dpp_mov<DPP_SHL4>(part);
+            const int tok = 2 * tq + tt;
+            if (c8i == 0) *reinterpret_cast<float*>(rb + ROFF_COEF + (half * 16 + tok) * 4) = part;
+            // raw r, k: only read as (token x, 4 channels) uint2 by the row waves; tokens >= 8 keep their 16-byte units swapped
+            // in pairs so that rows x and x + 8 (same bank at the 160-B stride) do not collide in that read
+            char* const rowz = rb + tok * RSB + ((ch0 * 2) ^ ((tok & 8) << 1));
+            *reinterpret_cast<uint2*>(rowz + R_R * ARR) = pr[tt];
+            *reinterpret_cast<uint2*>(rowz + R_K * ARR) = ck_[tt];
+            *reinterpret_cast<float4*>(rb + ROFF_LW + tok * FRS + ch0 * 4) = make_float4(clw[tt][0], clw[tt][1], clw[tt][2], clw[tt][3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                fr[c] = exp2_fast(cfr[tt][c]);
+                rh[c] = r[c] * fr[c];
+            }
+            char* const row = rb + tok * RSB + ch0 * 2;
+            uint2 hi, lo;
+            split4(rh, hi, lo);
+            *reinterpret_cast<uint2*>(row + R_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + R_RL * ARR) = lo;
+            *reinterpret_cast<float4*>(rb + ROFF_FR + tok * FRS + ch0 * 4) = make_float4(fr[0], fr[1], fr[2], fr[3]);
+        }
+        if (tq == 0)
+            *reinterpret_cast<float4*>(rb + ROFF_E8 + ch0 * 4) =
+                make_float4(exp2_fast(cc8[0]), exp2_fast(cc8[1]), exp2_fast(cc8[2]), exp2_fast(cc8[3]));
+    };
+
+    // ---- phase-C role
+    const int x = lane & 15, g = lane >> 4;
+    int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);          // transposed read, natural columns (own tile)
+    int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);          // transposed read, tile-labelled columns: + tile_tr(t)
+    // (explicit LDS address space: a volatile access through a generic pointer becomes a FLAT instruction whose wait drains the whole
+    // vector-memory queue)
+    typedef volatile int __attribute__((address_space(3))) lds_vint;
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    typedef volatile v4u_t __attribute__((address_space(3))) lds_vv4u;
+    // tag slot idx: the padding (bytes 128..159) of image rows 0, 1, 2 of the first array, eight per row
+    auto xflag_at = [&](int idx) { return (lds_vint*)(smem + (idx >> 3) * RSB + XFLAG_OFF + (idx & 7) * 4); };
+    if (tid < N_TAGS + 4) *xflag_at(tid) = 0;                     // (ordered before any use by the barrier that opens the first stage)
+    // Hand-over protocol.  Tile stores, tag stores, tag polls and tile loads are all volatile accesses: the compiler keeps their program
+    // order among themselves (and the LDS executes one wave's operations in order) without a full memory barrier, which would stop it
+    // from keeping the stage's many independent operand reads in flight around them.  The non-volatile operand reads that must stay
+    // behind a poll (take_gop) get their address through an `asm volatile` placed after the poll, and the publication that must stay
+    // behind them is preceded by an `asm volatile` that consumes their result: volatile asm statements and volatile accesses are not
+    // reordered among each other.  A tag is the stage index + 1 and every role executes every stage: a reader can only ever wait for
+    // a tag that some wave is about to write.
+    auto publish = [&](int idx, int tag) { if (lane == 0) *xflag_at(idx) = tag; };   // after this wave's (volatile) tile store
+#ifdef WKV6_DEBUG
+    // debug build: a poll that does not see its tag within ~2^22 tries writes (slot, tag index, expected, seen) to the debug buffer and traps
+    auto spin_fail = [&](int idx, int tag, unsigned seen) {
+        if (a.aux && lane == 0) {
+            unsigned* const d = reinterpret_cast<unsigned*>(a.aux);
+            d[0] = 0xdeadbeefu; d[1] = slot; d[2] = (unsigned)((wid << 8) | idx); d[3] = (unsigned)tag; d[4] = seen;
+        }
+        __builtin_trap();
+    };
+#define WKV6_SPIN_GUARD(idx, tag, seen) if (++spins > (1u << 22)) spin_fail(idx, tag, seen)
+#else
+#define WKV6_SPIN_GUARD(idx, tag, seen) do { } while (0)
+#endif
+    // readers poll two / four adjacent tags with one LDS round trip (a poll costs an LDS latency plus a drain of the wave's LDS queue)
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    auto await2 = [&](int idx, int tag) {
+        [[maybe_unused]] unsigned spins = 0;
+        for (;;) {
+            const v2u_t f = *(volatile v2u_t __attribute__((address_space(3)))*)xflag_at(idx);
+            if (__builtin_amdgcn_readfirstlane((int)((f.x ^ (unsigned)tag) | (f.y ^ (unsigned)tag))) == 0) break;
+            WKV6_SPIN_GUARD(idx, tag, f.x);
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto await4 = [&](int idx, int tag) {
+        [[maybe_unused]] unsigned spins = 0;
+        for (;;) {
+            const v4u_t f = *(lds_vv4u*)xflag_at(idx);
+            const unsigned t = (unsigned)tag;
+            if (__builtin_amdgcn_readfirstlane((int)((f.x ^ t) | (f.y ^ t) | (f.z ^ t) | (f.w ^ t))) == 0) break;
+            WKV6_SPIN_GUARD(idx, tag, f.x);
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto tile_store = [&](int off, uint2 hi, uint2 lo) {
+        *(lds_vv4u*)(smem + off + lane * 16) = v4u_t{hi.x, hi.y, lo.x, lo.y};
+    };
+    auto tile_load = [&](int off) {
+        const v4u_t f = *(lds_vv4u*)(smem + off + lane * 16);
+        return make_uint4(f.x, f.y, f.z, f.w);
+    };
+    if (producer) {
+        // =============== producers: R part of stage s-1 and K part of stage s-2 while stage s is consumed =====
+        if (ngrp > 0) {
+            load_kw(ngrp - 1);
+            load_r(ngrp - 1);
+            take_kw();
+            take_r();
+            if (ngrp > 1) load_kw(ngrp - 2);
+            prep_k(ngrp - 1);
+            prep_r(ngrp - 1);
+            if (ngrp > 1) {
+                take_kw();
+                load_r(ngrp - 2);
+                if (ngrp > 2) load_kw(ngrp - 3);
+                prep_k(ngrp - 2);
+            }
+        }
+        __syncthreads();
+        for (int grp = ngrp - 1; grp >= 0; --grp) {
+            WKV6_T(ts0);
+#ifdef WKV6_STAMP
+            asm volatile("" :: "v"(nr[0].x), "v"(nk[0].x), "v"(nr[1].x), "v"(nk[1].x));      // wait for the loads here
+#endif
+            WKV6_T(ts1);
+            if (grp > 0) {
+                // the consuming roles are light enough that a stage waits for the producers: the next requests go out BEFORE the
+                // preparation and fly during all of it
+                take_r();                                          // r of stage s-1
+                if (grp > 1) {
+                    take_kw();                                     // k, w of stage s-2
+                    load_r(grp - 2);
+                    if (grp > 2) load_kw(grp - 3);
+                }
+                WKV6_T(ts2);
+                prep_r(grp - 1);
+                if (grp > 1) prep_k(grp - 2);
+            }
+            WKV6_T(ts3);
+            __syncthreads();
+            WKV6_T(ts4);
+            WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3);
+        }
+    } else
+    if (rowrole) {
+        // =============== key rows [16wv, 16wv+16): gr, gk, gw, gu ==========================================
+        // ST[blk][jt][q] = S_entry(blk)[i = 16wv + x][j = tile_ch(jt) + 8g + q]   (transposed tiles: lane = key row)
+        float ue[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
+        f4v ST[SBLK][4];
+        float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // Checkpoint of the 64-token pair that holds stage `stg`: the forward wrote it in this wave's register order
+        // ([row wave][jt][lane][4], wkv6_scan.h: CKPT_ROW_ORDER), so the slice is four coalesced 16-byte loads per lane straight into
+        // registers.  Requested behind a stage's pre-phase (the registers of the stage's own states are dead by then) for the NEXT
+        // stage: the latency runs under the chain, the barrier and the next stage's tile work.  Both stages of a pair read the
+        // same checkpoint; the second read comes from the L2.
+        const unsigned nslots = ((unsigned)a.T + CKT - 1) / CKT;
+        const rsrc_t rs_ck = make_rsrc(a.ckpt + (long)(b * a.H + h) * nslots * (HEAD * HEAD), nslots * 16384u);
+        f4v CK[4];
+        auto request_ckpt = [&](int stg) {
+            const unsigned off = (unsigned)(stg >> 1) * 16384u + (unsigned)wv * 4096u + (unsigned)lane * 16u;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const float4 t = buf_load16f(rs_ck, off + jt * 1024u);
+                CK[jt] = f4v{t.x, t.y, t.z, t.w};
+            }
+        };
+        // S <- E16 (.) S + E16m8 (.) (Khat^T V): the state one block further, from that block's K part
+        auto advance = [&](const char* kb, const f4v (&Sin)[4], f4v (&Sout)[4]) {
+            const s4v khf = tr_read(kb + K_KH * ARR + troff + 32 * wv);
+            const s4v klf = tr_read(kb + K_KL * ARR + troff + 32 * wv);
+            const float e16 = *reinterpret_cast<const float*>(kb + KOFF_E16 + (16 * wv + x) * 4);
+            const float e16m8 = *reinterpret_cast<const float*>(kb + KOFF_E16M8 + (16 * wv + x) * 4);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const s4v vf = tr_read(kb + K_V * ARR + trow + tile_tr(jt));     // V[4g+e][tile_ch(jt) + 8(x>>2) + (x&3)]
+                f4v o = {0.f, 0.f, 0.f, 0.f};
+                o = mfma16(vf, khf, o);
+                o = mfma16(vf, klf, o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Sout[jt][q] = fmaf(e16, Sin[jt][q], e16m8 * o[q]);
+            }
+        };
+        if (ngrp > 0) request_ckpt(ngrp - 1);
+
+        __syncthreads();                                          // first stage image is ready
+        for (int grp = ngrp - 1; grp >= 0; --grp) {
+            WKV6_T(ts0);
+            // first of all, so that it is there long before the others ask for it:
+            if (wv >= 2) {   // this wave's dA tiles of the stage: block wv - 2, both orientations (tile 2 blk: dA[a][b], lane col b; 2 blk + 1:
+                             // dA^T[b][a], lane col a) from one pair of operand reads.  Row waves 0 and 1 make the score tiles instead.
+                const int tb = wv - 2;
+                const char* const rb = rpart(grp, tb);
+                const char* const kb = kpart(grp, tb);
+                f4v dA_ab = {0.f, 0.f, 0.f, 0.f}, dA_ba = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int off = x * RSB + (32 * s + 8 * g) * 2;
+                    const b8v gy_ = ld_b8(rb + R_GY * ARR + off), vr = ld_b8(kb + K_V * ARR + off);
+                    dA_ab = mfma32(gy_, vr, dA_ab);              // [row a][col b]: lane col b = x, rows a = 4g+q
+                    dA_ba = mfma32(vr, gy_, dA_ba);              // [row b][col a]: lane col a = x, rows b = 4g+q
+                }
+                float dab[4], dba[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 4 * g + q;
+                    dab[q] = x < o ? dA_ab[q] : 0.f;              // dA[a = o][b = x], strictly lower
+                    dba[q] = o < x ? dA_ba[q] : 0.f;              // dA^T[b = o][a = x], strictly lower
+                }
+                uint2 th, tl;
+                split4(dab, th, tl);
+                tile_store(XT_OFF + (2 * tb) * 1024, th, tl);
+                publish(TAG_DA + 2 * tb, grp + 1);
+                split4(dba, th, tl);
+                tile_store(XT_OFF + (2 * tb + 1) * 1024, th, tl);
+                publish(TAG_DA + 2 * tb + 1, grp + 1);
+            } else {         // row waves 0 and 1: the masked score tile of block wv, for the column waves
+                const char* const rb = rpart(grp, wv);
+                const char* const kb = kpart(grp, wv);
+                f4v sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int off = x * RSB + (32 * s + 8 * g) * 2;
+                    const b8v rh = ld_b8(rb + R_RH * ARR + off), rl = ld_b8(rb + R_RL * ARR + off);
+                    const b8v kh = ld_b8(kb + K_KH * ARR + off), kl = ld_b8(kb + K_KL * ARR + off);
+                    sc = mfma32(rh, kh, sc);                  // A[row a][col b]: lane col b = x, rows a = 4g+q
+                    sc = mfma32(rh, kl, sc);
+                    sc = mfma32(rl, kh, sc);
+                }
+                const float4 cfa = *reinterpret_cast<const float4*>(rb + ROFF_COEF + 16 * g);
+                const float4 cfb = *reinterpret_cast<const float4*>(rb + ROFF_COEF + 64 + 16 * g);
+                const float cf[4] = {cfa.x + cfb.x, cfa.y + cfb.y, cfa.z + cfb.z, cfa.w + cfb.w};
+                float scm[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 4 * g + q;                  // query token a; key token b = x
+                    scm[q] = x < o ? sc[q] : (x == o ? cf[q] : 0.f);
+                }
+                uint2 th, tl;
+                split4(scm, th, tl);
+                tile_store(XS_OFF + wv * 1024, th, tl);
+                publish(TAG_SC + wv, grp + 1);
+            }
+            // stage-entry forward state: the checkpoint of this 64-token pair (requested a stage's chain ago); the odd stage of a pair
+            // first walks it through the two blocks of the even stage in front (their K part is already in the ring)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) ST[0][jt] = CK[jt];
+            WKV6_T(ts1);
+            if (grp & 1) {
+                advance(kpart(grp - 1, 0), ST[0], ST[0]);
+                advance(kpart(grp - 1, 1), ST[0], ST[0]);
+            }
+            // ---- rebuild the entry state of block 1
+#pragma unroll
+            for (int blk = 0; blk < SBLK - 1; ++blk) advance(kpart(grp, blk), ST[blk], ST[blk + 1]);
+            WKV6_T(ts2);
+            // ---- G-dependent part of gk, decoupled from the epilogues: sum_j (E16m8 G)[i][j] v_b[j] per block from the operand
+            //      the column waves publish; block 1's version is taken (and released: GB) here, block 0's behind the pre-phase
+            f4v gvb[SBLK];
+            auto take_gop = [&](int blk) {
+                int base_ = GOP_OFF + (8 * g + (x >> 2)) * GRS + (16 * wv + 4 * (x & 3)) * 2;
+                asm volatile("" : "+v"(base_));                    // keeps the reads behind the tag polls that precede the call
+                typedef short s8v __attribute__((ext_vector_type(8)));
+                const char* const kb = kpart(grp, blk);
+                f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {   // lane (x, g): key row 16wv + x, value columns 32s + 8g .. +7 (stored [j][i]: transposing reads)
+                    const char* const ph = smem + base_ + 32 * s * GRS;
+                    const s8v h8 = __builtin_shufflevector(tr_read(ph), tr_read(ph + 4 * GRS), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s8v l8 = __builtin_shufflevector(tr_read(ph + HEAD * GRS), tr_read(ph + HEAD * GRS + 4 * GRS), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const b8v vr = ld_b8(kb + K_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
+                    acc = mfma32(__builtin_bit_cast(b8v, h8), vr, acc);
+                    acc = mfma32(__builtin_bit_cast(b8v, l8), vr, acc);
+                }
+                return acc;
+            };
+            await4(TAG_GA, grp + 1);
+            gvb[1] = take_gop(1);
+            asm volatile("" :: "v"(gvb[1]));                   // (the operand reads have returned)
+            publish(TAG_GB + wv, grp + 1);
+            // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
+            //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
+            f4v ackp[SBLK];
+            float at[SBLK][4], vgs[SBLK];
+#pragma unroll
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                const char* const rb = rpart(grp, blk);
+                const char* const kb = kpart(grp, blk);
+                float old_gr[4] = {0.f, 0.f, 0.f, 0.f};
+                fetch_old(0, ogr, grp * STG + blk * BLK + x, REV_R, 16 * wv + 4 * g, old_gr);
+                b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: the B operand of accs
+#pragma unroll
+                for (int s = 0; s < 2; ++s) gyr[s] = ld_b8(rb + R_GY * ARR + x * RSB + (32 * s + 8 * g) * 2);
+                // vg_x = dA[x][x] = gy_x . v_x: the two half sums
+                const float vg = *reinterpret_cast<const float*>(rb + ROFF_VG + x * 4) + *reinterpret_cast<const float*>(rb + ROFF_VG + 64 + x * 4);
+                vgs[blk] = vg;
+                if (blk == SBLK - 1) await4(TAG_DA, grp + 1);     // all four dA tiles of the stage with one poll
+                const uint4 fab = tile_load(XT_OFF + (2 * blk) * 1024), fba = tile_load(XT_OFF + (2 * blk + 1) * 1024);
+                const s4v dab_hi = __builtin_bit_cast(s4v, make_uint2(fab.x, fab.y)), dab_lo = __builtin_bit_cast(s4v, make_uint2(fab.z, fab.w));
+                const s4v dba_hi = __builtin_bit_cast(s4v, make_uint2(fba.x, fba.y)), dba_lo = __builtin_bit_cast(s4v, make_uint2(fba.z, fba.w));
+                const s4v rhf_w = tr_read(rb + R_RH * ARR + troff + 32 * wv);      // Rhat[4g+e][16wv + x]
+                const s4v rlf_w = tr_read(rb + R_RL * ARR + troff + 32 * wv);
+                const s4v khf = tr_read(kb + K_KH * ARR + troff + 32 * wv);
+                const s4v klf = tr_read(kb + K_KL * ARR + troff + 32 * wv);
+                // gr accumulator [i_local = 4g+q][token x].  E8 scales key rows = output rows here, so it is applied to the 4
+                // results instead of the 16 operand values (the state tiles are dead after this: split in place, no copy)
+                const float4 e8o = *reinterpret_cast<const float4*>(rb + ROFF_E8 + (16 * wv + 4 * g) * 4);
+                f4v accs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float t0[4], t1[4];
+                    b8v hi, lo;                                  // k-slot (s, g, e) <-> value channel 32s + 8g + e
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q]; t1[q] = ST[blk][2 * s + 1][q]; }
+                    split8(t0, t1, hi, lo);
+                    accs = mfma32(hi, gyr[s], accs);
+                    accs = mfma32(lo, gyr[s], accs);
+                }
+                f4v accr16 = {0.f, 0.f, 0.f, 0.f};               // separate accumulator per MFMA shape (see wkv6_chunk.hip)
+                accr16 = mfma16(khf, dba_hi, accr16);            // sum_b Khat[b][i] dA[a][b]
+                accr16 = mfma16(khf, dba_lo, accr16);
+                accr16 = mfma16(klf, dba_hi, accr16);
+                const f4v accr = {fmaf(e8o.x, accs[0], accr16[0]), fmaf(e8o.y, accs[1], accr16[1]),
+                                  fmaf(e8o.z, accs[2], accr16[2]), fmaf(e8o.w, accs[3], accr16[3])};
+                f4v ak = {0.f, 0.f, 0.f, 0.f};
+                ak = mfma16(rhf_w, dab_hi, ak);                  // sum_a Rhat[a][i] dA[a][b]
+                ak = mfma16(rhf_w, dab_lo, ak);
+                ak = mfma16(rlf_w, dab_hi, ak);
+                ackp[blk] = ak;
+                {   // gr, a_t, gu: lane = token x, channels ch .. ch+3
+                    const int ch = 16 * wv + 4 * g;
+                    const float4 fr4 = *reinterpret_cast<const float4*>(rb + ROFF_FR + x * FRS + ch * 4);
+                    const uint2 rr = *reinterpret_cast<const uint2*>(rb + R_R * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
+                    const uint2 kk = *reinterpret_cast<const uint2*>(rb + R_K * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
+                    const float frv[4] = {fr4.x, fr4.y, fr4.z, fr4.w};
+                    const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                    const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
+                    float o_gr[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dq = frv[q] * accr[q];
+                        o_gr[q] = fmaf(vg * ue[q], kv[q], dq);
+                        gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
+                        at[blk][q] = rv[q] * dq;
+                    }
+                    const int p = grp * STG + blk * BLK + x;
+                    emit(0, rs_gr, ogr, p, REV_R, ch, o_gr, old_gr);
+                }
+            }
+            WKV6_T(ts3);
+            // the next stage's checkpoint: the state registers of this stage are dead from here on
+            if (grp > 0) request_ckpt(grp - 1);
+            await4(TAG_GC, grp + 1);
+            gvb[0] = take_gop(0);
+            // ---- chain: only the work that needs G
+#pragma unroll
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                const char* const rb = rpart(grp, blk);
+                const char* const kb = kpart(grp, blk);
+                float old_gk[4] = {0.f, 0.f, 0.f, 0.f}, old_gw[4] = {0.f, 0.f, 0.f, 0.f};
+                fetch_old(1, ogk, grp * STG + blk * BLK + x, REV_K, 16 * wv + 4 * g, old_gk);
+                fetch_old(3, ogw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw);
+                f4v acck = gvb[blk];
+                acck += ackp[blk];
+                {
+                    const int ch = 16 * wv + 4 * g;
+                    const float4 fn4 = *reinterpret_cast<const float4*>(x < 15 ? rb + ROFF_FR + (x + 1) * FRS + ch * 4 : kb + KOFF_E16M8 + ch * 4);
+                    const float4 fk4 = make_float4(__builtin_amdgcn_rcpf(fn4.x), __builtin_amdgcn_rcpf(fn4.y), __builtin_amdgcn_rcpf(fn4.z),
+                                                   __builtin_amdgcn_rcpf(fn4.w));      // fK_x = 1 / fR_{x+1}
+                    const float4 lw4 = *reinterpret_cast<const float4*>(rb + ROFF_LW + x * FRS + ch * 4);
+                    const uint2 rr = *reinterpret_cast<const uint2*>(rb + R_R * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
+                    const uint2 kk = *reinterpret_cast<const uint2*>(rb + R_K * ARR + x * RSB + ((ch * 2) ^ ((x & 8) << 1)));
+                    const float fkv[4] = {fk4.x, fk4.y, fk4.z, fk4.w}, lwv[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
+                    const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                    const float kv[4] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y)};
+                    const float vg = vgs[blk];
+                    float o_gk[4], o_gw[4], bt[4], dl[4], sfx[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dk = fkv[q] * acck[q];
+                        o_gk[q] = fmaf(vg * ue[q], rv[q], dk);
+                        bt[q] = kv[q] * dk;
+                        dl[q] = at[blk][q] - bt[q];
+                        sfx[q] = dl[q];
+                    }
+                    WKV6_DPP_ACC4(sfx, "row_shl:1");      // inclusive suffix sums over the later tokens of the row
+                    WKV6_DPP_ACC4(sfx, "row_shl:2");
+                    WKV6_DPP_ACC4(sfx, "row_shl:4");
+                    WKV6_DPP_ACC4(sfx, "row_shl:8");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float total = dpp_mov<DPP_BCAST0>(sfx[q]);   // token 0 of the row holds the block total
+                        o_gw[q] = (Rc[q] + (sfx[q] - dl[q]) - bt[q]) * lwv[q];
+                        Rc[q] += total;
+                    }
+                    const int p = grp * STG + blk * BLK + x;
+                    emit(1, rs_gk, ogk, p, REV_K, ch, o_gk, old_gk);
+                    emit(3, rs_gw, ogw, p, REV_W, ch, o_gw, old_gw);
+                }
+            }
+            WKV6_T(ts4);
+            __syncthreads();
+            WKV6_T(ts5);
+            WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3); WKV6_ACC(4, ts5, ts4);
+        }
+        if (a.gu) {
+            float s4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] = row_sum16(gu_acc[q]);
+            const long o = (long)b * a.C + h * HEAD + 16 * wv + 4 * g;
+            if (x == 0) {
+                if (a.part_f32) io4<float>::store(reinterpret_cast<float*>(a.gu) + o, s4);
+                else io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.gu) + o, s4);
+            }
+        }
+    } else {
+        // =============== value columns [16wv, 16wv+16): G, gv, gs ======================================
+        // GJ[it][q] = G[i = tile_ch(it) + 8g + q][j = 16wv + x]
+        f4v GJ[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) GJ[t] = f4v{0.f, 0.f, 0.f, 0.f};
+        // this wave's share of the PREPARATION: v (K part, stage s-2) and gy (R part, stage s-1) of tokens 4wv .. 4wv+3 of both blocks go from
+        // global memory into the images, with the two half sums of vg_a = gy_a . v_a (the v of a stage is kept in registers for the one
+        // iteration until its gy arrives).  lane = (token tl, channels 4cl .. 4cl+3); requested at the head of a stage, written at its end.
+        const int tl = lane >> 4, cl = lane & 15;
+        uint2 cv[SBLK], cg[SBLK], cvp[SBLK];
+        auto load_v = [&](int stg) {
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                const int p = stg * STG + blk * BLK + 4 * wv + tl;
+                cv[blk] = buf_load8(rs_v, (unsigned)(tokmap(p, REV_V) * a.C + 4 * cl) * 2u);
+            }
+        };
+        auto load_gy = [&](int stg) {
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                const int p = stg * STG + blk * BLK + 4 * wv + tl;
+                cg[blk] = buf_load8(rs_g, (unsigned)(tokmap(p, REV_Y) * a.C + 4 * cl) * 2u);
+            }
+        };
+        auto copy_v = [&](int stg) {       // cv -> K part of stage stg; kept in cvp for the stage's vg
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                *reinterpret_cast<uint2*>(kpart(stg, blk) + K_V * ARR + (4 * wv + tl) * RSB + 8 * cl) = cv[blk];
+                cvp[blk] = cv[blk];
+            }
+        };
+        auto copy_gy = [&](int stg) {      // cg -> R part of stage stg, with vg from cvp (= v of the same stage)
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                char* const rb = rpart(stg, blk);
+                const int tok = 4 * wv + tl;
+                *reinterpret_cast<uint2*>(rb + R_GY * ARR + tok * RSB + 8 * cl) = cg[blk];
+                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                float vg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, cg[blk].x), __builtin_bit_cast(bf2, cvp[blk].x), 0.f, false);
+                vg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, cg[blk].y), __builtin_bit_cast(bf2, cvp[blk].y), vg, false);
+                vg += dpp_mov<DPP_XOR1>(vg);                       // the two 32-channel half sums, formed exactly as the producers of the
+                vg += dpp_mov<DPP_XOR2>(vg);                       // split kernels form them (same results bit for bit)
+                vg += dpp_mov<DPP_SHL4>(vg);
+                if ((cl & 7) == 0) *reinterpret_cast<float*>(rb + ROFF_VG + ((cl >> 3) * 16 + tok) * 4) = vg;
+            }
+        };
+        if (ngrp > 0) {
+            load_v(ngrp - 1);
+            load_gy(ngrp - 1);
+            copy_v(ngrp - 1);
+            copy_gy(ngrp - 1);
+            if (ngrp > 1) {
+                load_v(ngrp - 2);
+                copy_v(ngrp - 2);
+            }
+        }
+        __syncthreads();                                          // first stage image is ready
+        for (int grp = ngrp - 1; grp >= 0; --grp) {
+            WKV6_T(ts0);
+            if (grp > 0) load_gy(grp - 1);
+            if (grp > 1) load_v(grp - 2);
+            // ---- the stage's G recurrence, first thing: per block (1, then 0) scale by E16m8, split, publish the operand for the row
+            // waves (stored [j][i]: this lane's 16 bytes are key rows 32s + 8g .. +7 of value column 16wv + x), keep the fragments for
+            // this wave's own chain, and move G to the entry of the block
+            s4v gyT_w[SBLK], sc_hi[SBLK], sc_lo[SBLK];
+            f4v accp[SBLK];
+            b8v gh[SBLK][2], gl[SBLK][2];
+#pragma unroll
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                const char* const rb = rpart(grp, blk);
+                const char* const kb = kpart(grp, blk);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float t0[4], t1[4];
+                    const float4 m0 = *reinterpret_cast<const float4*>(kb + KOFF_E16M8 + (32 * s + 8 * g) * 4);
+                    const float4 m1 = *reinterpret_cast<const float4*>(kb + KOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
+                    t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
+                    t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
+                    t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
+                    split8(t0, t1, gh[blk][s], gl[blk][s]);
+                }
+                if (blk == 0) {
+                    await4(TAG_GB, grp + 1);     // the row waves have taken block 1's version
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    char* const dst = smem + GOP_OFF + (16 * wv + x) * GRS + (32 * s + 8 * g) * 2;
+                    *(lds_vv4u*)dst = __builtin_bit_cast(v4u_t, gh[blk][s]);
+                    *(lds_vv4u*)(dst + HEAD * GRS) = __builtin_bit_cast(v4u_t, gl[blk][s]);
+                }
+                publish((blk ? TAG_GA : TAG_GC) + wv, grp + 1);
+                const s4v gyT = tr_read(rb + R_GY * ARR + troff + 32 * wv);           // gy[4g+e][16wv + x]
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {              // (Rhat^T gy) tile [row i_local][col j_local = x];  G <- E16 G + E8 (Rhat^T gy)
+                    const s4v rhf = tr_read(rb + R_RH * ARR + trow + tile_tr(it));
+                    const s4v rlf = tr_read(rb + R_RL * ARR + trow + tile_tr(it));
+                    f4v o = {0.f, 0.f, 0.f, 0.f};
+                    o = mfma16(rhf, gyT, o);
+                    o = mfma16(rlf, gyT, o);
+                    const float4 d16 = *reinterpret_cast<const float4*>(kb + KOFF_E16 + (tile_ch(it) + 8 * g) * 4);
+                    const float4 d8 = *reinterpret_cast<const float4*>(rb + ROFF_E8 + (tile_ch(it) + 8 * g) * 4);
+                    GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * o[0]);
+                    GJ[it][1] = fmaf(d16.y, GJ[it][1], d8.y * o[1]);
+                    GJ[it][2] = fmaf(d16.z, GJ[it][2], d8.z * o[2]);
+                    GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * o[3]);
+                }
+            }
+            // ---- pre-phase: everything that does not depend on G
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) gyT_w[blk] = tr_read(rpart(grp, blk) + R_GY * ARR + troff + 32 * wv);   // gy[4g+e][16wv + x]
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                if (blk == 0) await2(TAG_SC, grp + 1);        // both score tiles with one poll
+                const uint4 f = tile_load(XS_OFF + blk * 1024);
+                sc_hi[blk] = __builtin_bit_cast(s4v, make_uint2(f.x, f.y));
+                sc_lo[blk] = __builtin_bit_cast(s4v, make_uint2(f.z, f.w));
+            }
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) {
+                f4v acc = {0.f, 0.f, 0.f, 0.f};               // gv^T[j][b], first part: sum_a gy[a][j] A[a][b]
+                acc = mfma16(gyT_w[blk], sc_hi[blk], acc);
+                acc = mfma16(gyT_w[blk], sc_lo[blk], acc);
+                accp[blk] = acc;
+            }
+            WKV6_T(ts1);
+            // ---- chain: only the work that needs G
+#pragma unroll
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                const char* const kb = kpart(grp, blk);
+                float old_gv[4] = {0.f, 0.f, 0.f, 0.f};
+                fetch_old(2, ogv, grp * STG + blk * BLK + x, REV_V, 16 * wv + 4 * g, old_gv);
+                f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int off = x * RSB + (32 * s + 8 * g) * 2;
+                    const b8v kh = ld_b8(kb + K_KH * ARR + off), kl = ld_b8(kb + K_KL * ARR + off);
+                    acc = mfma32(gh[blk][s], kh, acc);       // k-slot (s, g, e) <-> key channel 32s + 8g + e
+                    acc = mfma32(gh[blk][s], kl, acc);
+                    acc = mfma32(gl[blk][s], kh, acc);
+                }
+                acc += accp[blk];
+                {
+                    const int p = grp * STG + blk * BLK + x;
+                    float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+                    emit(2, rs_gv, ogv, p, REV_V, 16 * wv + 4 * g, o, old_gv);
+                }
+            }
+            if (grp > 0) copy_gy(grp - 1);                     // (uses cvp = v of stage s-1, before copy_v replaces it)
+            if (grp > 1) copy_v(grp - 2);
+            WKV6_T(ts2);
+            __syncthreads();
+            WKV6_T(ts3);
+            WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2);
+        }
+        if (a.gs) {   // dL/dS0, layout [j][i]
+            const long so_ = ((long)b * a.H + h) * HEAD * HEAD + (long)(16 * wv + x) * HEAD + 8 * g;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float t4[4] = {GJ[it][0], GJ[it][1], GJ[it][2], GJ[it][3]};
+                if (a.part_f32) io4<float>::store(reinterpret_cast<float*>(a.gs) + so_ + tile_ch(it), t4);
+                else io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.gs) + so_ + tile_ch(it), t4);
+            }
+        }
+    }
+#ifdef WKV6_DEBUGBUF
+    WKV6_CLK(clk1, rtc1);
+    if (a.aux && lane == 0) {
+        unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)bh * 16 + wid) * 8;
+#ifdef WKV6_STAMP
+        for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
+#endif
+        d[6] = clk1 - clk0;
+        d[7] = rtc1 - rtc0;
+    }
+#endif
+    if (GEN == 1 && a.zero_tail) {
+        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = ntok + (tid >> 4); t < a.T; t += (int)(blockDim.x >> 4)) {
+            const unsigned idx = (unsigned)(t * a.C + 4 * (tid & 15));
+            io4<bf16_t>::store(ogr + idx, z);
+            io4<bf16_t>::store(ogk + idx, z);
+            io4<bf16_t>::store(ogv + idx, z);
+            io4<bf16_t>::store(ogw + idx, z);
+        }
+    }
+}
+
+template <bool W_RAW, int GEN>
+__global__ __launch_bounds__(768) void chunk_bwd12k_kernel(const ScanArgs a)
+{
+    chunk_bwd12k_body<W_RAW, GEN>(a, blockIdx.x);
+}
+
+// the backward of chunk_fwd_pair_kernel (wkv6_chunk.hip): two problems of one shape, slots [0, B H) serve a0, the rest a1
+template <bool W_RAW>
+__global__ __launch_bounds__(768) void chunk_bwd12k_pair_kernel(const ScanArgs a0, const ScanArgs a1)
+{
+    const unsigned n = (unsigned)(a0.B * a0.H);
+    const bool second = blockIdx.x >= n;
+    chunk_bwd12k_body<W_RAW, 0>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);
+}
+
+template <bool W_RAW, int GEN> hipError_t launch_bwd12k_inst(const ScanArgs& a, hipStream_t st)
+{
+    constexpr size_t lds = BWD12K_LDS;
+    static LdsAttrOnce attr;                   // per instantiation and device
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12k_kernel<W_RAW, GEN>), lds)) return e;
+    hipLaunchKernelGGL((chunk_bwd12k_kernel<W_RAW, GEN>), dim3(a.B * a.H), dim3(768), lds, st, a);
+    return hipGetLastError();
+}
+template <bool W_RAW> hipError_t launch_bwd12k_variant(const ScanArgs& a, hipStream_t st)
+{
+    if (a.accumulate) return launch_bwd12k_inst<W_RAW, 2>(a, st);
+    const bool first_half = a.zero_tail || a.g_f32[0] || a.g_f32[1] || a.g_f32[2] || a.g_f32[3];
+    return first_half ? launch_bwd12k_inst<W_RAW, 1>(a, st) : launch_bwd12k_inst<W_RAW, 0>(a, st);
+}
+
+}  // namespace
+
+// reverse pass over 64-token row-order checkpoints (a.ckpt filled by the forward or by launch_chunk_state_pass); unsplit launches only
+hipError_t launch_chunk_bwd12k(const ScanArgs& a_, hipStream_t st)
+{
+    if (a_.ckpt_tok != CKT || a_.ckpt_fmt != CKPT_ROW_ORDER || a_.split || !a_.ckpt) return hipErrorInvalidValue;
+#ifdef WKV6_DEBUGBUF
+    ScanArgs a = a_;
+    a.aux = reinterpret_cast<float*>(g_stamp_buffer);
+#else
+    const ScanArgs& a = a_;
+#endif
+    return a.wkind ? launch_bwd12k_variant<true>(a, st) : launch_bwd12k_variant<false>(a, st);
+}
+
+hipError_t launch_chunk_bwd12k_pair(const ScanArgs& a0, const ScanArgs& a1, hipStream_t st)
+{
+    constexpr size_t lds = BWD12K_LDS;
+    static LdsAttrOnce attr_raw, attr_ew;
+    if (a0.wkind == 1) {
+        if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_bwd12k_pair_kernel<true>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_pair_kernel<true>), dim3(2 * a0.B * a0.H), dim3(768), lds, st, a0, a1);
+    } else {
+        if (hipError_t e = attr_ew.ensure(reinterpret_cast<const void*>(chunk_bwd12k_pair_kernel<false>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_pair_kernel<false>), dim3(2 * a0.B * a0.H), dim3(768), lds, st, a0, a1);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace wkv6

@@ -1,7 +1,11 @@
-"""GPU parity of the two-level backward (csrc/wkv6_chunk_bwd64.hip: 64-token chunks, integer reference frames, 64-token
-checkpoints), the opt-in kernel behind WKV6_BWD=64, at the same bf16 contract as the default 12-wave backward: golden vectors
-generated from the reference, the oracle on random shapes, the exact scan kernels at every block / chunk boundary, the wkv6_bi and
-in-kernel-reversal store paths, and config 2 at full size."""
+"""GPU parity of the two backward kernels that read 64-token checkpoints, forced onto every shape of the suite:
+  * `12k` -- csrc/wkv6_chunk_bwd12k.hip, the DEFAULT backward of launches with one workgroup per (batch, head) (row-order checkpoints,
+    K part of the stage image two stages ahead); the suite's small shapes would otherwise run two workgroups per pair
+    (wkv6_chunk_bwd12.hip), so WKV6_SPLIT=0 puts them on this kernel;
+  * `64`  -- csrc/wkv6_chunk_bwd64.hip, the two-level experiment behind WKV6_BWD=64 (integer reference frames);
+at the same bf16 contract as everything else: golden vectors generated from the reference, the oracle on random shapes, the exact
+scan kernels at every block / stage / checkpoint boundary, the wkv6_bi and in-kernel-reversal store paths, and config 2 at full
+size against oracle slices and the 32-token-checkpoint kernel (WKV6_BWD=32)."""
 import numpy as np
 import pytest
 import torch
@@ -21,13 +25,20 @@ def ops():
     return wkv6_op
 
 
-@pytest.fixture
-def two_level(monkeypatch):
-    """Select the two-level backward for every shape (the library reads the switches at each call); the forward then leaves its
-    checkpoints 64 tokens apart.  WKV6_SPLIT=0: small (batch, head) counts would otherwise keep the 12-wave kernel, the only one
-    that can put two workgroups on one pair."""
-    monkeypatch.setenv("WKV6_BWD", "64")
-    monkeypatch.setenv("WKV6_SPLIT", "0")
+@pytest.fixture(params=["12k", "64"])
+def two_level(monkeypatch, request):
+    """Select one of the 64-token-checkpoint backward kernels for every shape (the library reads the switches at each call); the
+    forward then leaves its checkpoints 64 tokens apart.  WKV6_SPLIT=0: small (batch, head) counts would otherwise run two
+    workgroups per pair on the 32-token kernel, the only one that can.  Returns a function that re-selects the kernel (for tests
+    that switch to the 32-token kernel for a reference run)."""
+    def select():
+        if request.param == "64":
+            monkeypatch.setenv("WKV6_BWD", "64")
+        else:
+            monkeypatch.delenv("WKV6_BWD", raising=False)
+        monkeypatch.setenv("WKV6_SPLIT", "0")
+    select()
+    return select
 
 
 @pytest.mark.parametrize("name", ["wkv6_init", "wkv6_stress", "wkv6_extreme", "wkv6_T1", "wkv6_T2", "wkv6_T3", "wkv6_state", "wkv6_infctx"])
@@ -146,11 +157,11 @@ def test_in_kernel_reversal(ops, two_level, monkeypatch):
         ck = ops.new_checkpoint(B, T, H * 64, H, "cuda")
         ops.forward_rev_ex(*d[:5], H, rev_n, mask, ckpt=ck)
         got = ops.backward_rev_ex(*d, H, rev_n, mask, ckpt=ck)
-        monkeypatch.setenv("WKV6_BWD", "12")
+        monkeypatch.setenv("WKV6_BWD", "32")
         ck12 = ops.new_checkpoint(B, T, H * 64, H, "cuda")
         ops.forward_rev_ex(*d[:5], H, rev_n, mask, ckpt=ck12)
         ref = ops.backward_rev_ex(*d, H, rev_n, mask, ckpt=ck12)
-        monkeypatch.setenv("WKV6_BWD", "64")
+        two_level()
         for n, a, b in zip(("gr", "gk", "gv", "gw", "gu"), got, ref):
             a, b = host(a), host(b)
             scale = max(float(np.abs(b).max()), 1e-3)
@@ -178,7 +189,7 @@ def test_config2_full_size_vs_oracle_slices_and_12_wave(ops, oracle, two_level, 
     C = H * 64
     r, k, v, w, u, gy = synth(B, T, H, torch.device("cuda", 0))
     ck = ops.new_checkpoint(B, T, C, H, r.device)
-    assert ck.numel() == B * T * C * 4                            # 4 B per token-channel (the 12-wave kernel keeps 8)
+    assert ck.numel() == B * T * C * 4                            # 4 B per token-channel
     ops.forward_ex(r, k, v, w, u, H, ckpt=ck)
     gr, gk, gv, gw, gu, _ = ops.backward_ex(r, k, v, w, u, gy, H, ckpt=ck)
     for (b, h) in ((0, 0), (7, 31), (3, 16)):
@@ -192,8 +203,9 @@ def test_config2_full_size_vs_oracle_slices_and_12_wave(ops, oracle, two_level, 
         rms, off, ulps = bf16_report(host(gw[sl]), og["gw"], floor=0.1)
         assert rms <= 1e-3 and ulps <= 2.0 and off <= 0.10, (b, h, rms, off, ulps)
         assert max_norm_err(host(gu[b, 64 * h:64 * h + 64]), og["gu_b"][0]) <= 1e-3
-    monkeypatch.setenv("WKV6_BWD", "12")
+    monkeypatch.setenv("WKV6_BWD", "32")
     ck12 = ops.new_checkpoint(B, T, C, H, r.device)
+    assert ck12.numel() == B * T * C * 8                          # the 32-token kernel keeps 8 B per token-channel
     ops.forward_ex(r, k, v, w, u, H, ckpt=ck12)
     ref = ops.backward_ex(r, k, v, w, u, gy, H, ckpt=ck12)
     for n, a, b_ in zip(("gr", "gk", "gv", "gw"), (gr, gk, gv, gw), ref):

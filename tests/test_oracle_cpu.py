@@ -129,8 +129,8 @@ def test_abi_rejects_bad_arguments_without_launching():
     assert lib.wkv6_cuda_forward(1, 4, 64, 1, None, 1, 1, 1, 1, 1, None) == -2
     assert lib.wkv6state_cuda_forward(1, 4, 64, 1, 1, 1, 1, 1, 1, None, 1, None) == -2
     assert lib.wkv6_backward_ex(1, 4, 64, 1, 1, 1, 1, 1, 1, None, 1, 1, 1, 1, 1, None, None, 1, 16, 1, None) == -3
-    # max(scan scratch fp32 [B,T,C], one 64x64 fp32 forward state per (batch, head) and 32-token stage)
-    assert lib.wkv6_backward_workspace_bytes(8, 4096, 2048, 32) == 8 * 32 * (4096 // 32) * 64 * 64 * 4
+    # max(scan scratch fp32 [B,T,C], one 64x64 fp32 forward state per (batch, head) and 64 tokens) -- equal: 4 B per token-channel
+    assert lib.wkv6_backward_workspace_bytes(8, 4096, 2048, 32) == 8 * 32 * (4096 // 64) * 64 * 64 * 4
     assert lib.wkv6_backward_workspace_bytes(1, 16, 64, 1) == max(1 * 16 * 64 * 4, 64 * 64 * 4)
     # lens | 2 scan workspaces (one per direction) | 4 fp32 [B,T,C] side buffers, each 256-byte aligned
     assert lib.wkv6bi_workspace_bytes(2, 16, 64, 1) == 256 + 2 * (2 * 1 * 64 * 64 * 4) + 4 * (2 * 16 * 64 * 4)

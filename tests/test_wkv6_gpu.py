@@ -176,16 +176,17 @@ def test_golden_bi(ops, io):
     assert max_norm_err(host(gu).sum(0).reshape(H, 64), g["gu"]) <= (F32_TOL if io == torch.float32 else PART_TOL)
 
 
-@pytest.mark.parametrize("bwd", ["12", "64"], ids=["bwd12", "bwd64"])
+@pytest.mark.parametrize("bwd", ["auto", "12k", "64"], ids=["auto", "bwd12k", "bwd64"])
 @pytest.mark.parametrize("io", IOS, ids=["f32", "bf16"])
 def test_golden_medium(ops, monkeypatch, io, bwd):
     """Reference-generated vectors at T = 160 (oracle/gen_golden_medium.py): every block, stage, group and checkpoint boundary of
     the chunked kernels meets values that came out of the reference's own recurrence -- plain, per-sample state with gs and
     final state, ragged wkv6_bi; fp32 I/O (scan kernels) and bf16 I/O through either chunked backward."""
-    if bwd == "64":
+    if bwd != "auto":      # auto: the small grid runs two workgroups per pair (32-token kernel); 12k: the default unsplit kernel; 64: two-level
         if io == torch.float32:
             pytest.skip("the backward switch only concerns the chunked bf16 kernels")
-        monkeypatch.setenv("WKV6_BWD", "64")
+        if bwd == "64":
+            monkeypatch.setenv("WKV6_BWD", "64")
         monkeypatch.setenv("WKV6_SPLIT", "0")
     tol = F32_TOL if io == torch.float32 else PART_TOL
     g = load_golden_mid("wkv6_mid")
@@ -287,8 +288,10 @@ def test_autograd_surface(ops, oracle):
 
 def test_two_workgroups_per_head_is_the_same_arithmetic(ops, monkeypatch):
     """Few (batch, head) pairs (B*H <= half the CUs) run as two workgroups per pair -- forward: two consumer waves each, backward:
-    row role / column role -- with the same per-wave arithmetic: every output is bit-identical to the one-workgroup launch
-    (WKV6_SPLIT forces either; the default picks by grid size, so the suite's small cases run split and the full-size ones not)."""
+    row role / column role of the 32-token-checkpoint kernel -- with the same per-wave arithmetic: every output is bit-identical to
+    the one-workgroup launch of the same kernel family (WKV6_BWD=32; WKV6_SPLIT forces either mode; the default picks by grid size,
+    so the suite's small cases run split and the full-size ones not)."""
+    monkeypatch.setenv("WKV6_BWD", "32")
     bf = torch.bfloat16
     B, T, H = 3, 200, 2
     r, k, v, w, u, gy = rand_inputs(11, B, T, H)
