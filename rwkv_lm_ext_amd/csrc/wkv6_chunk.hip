@@ -350,9 +350,11 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 #pragma unroll unroll_by
             for (int blk = 0; blk < nb; ++blk) {
                 const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                v4u ckd[4];
+                int ck_off = -1;                                  // >= 0: a row-order checkpoint waits in ckd for its stores
                 if (a.ckpt && ((unsigned)(blk * BLK) & (ckt - 1)) == 0) {   // state every ckpt_tok tokens, for the backward kernel (slots past T: dropped)
                     const unsigned st = (unsigned)(grp * GRP + blk * BLK) >> cksh;
-                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
                     if (a.ckpt_fmt == CKPT_ROW_ORDER) {
                         // The backward's row waves want key row i on the lane and four consecutive value columns per register quad;
                         // here a lane holds one value column j and four consecutive key rows per quad.  The 64 x 16 slice of this
@@ -360,7 +362,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                         //     jl0 | jl1 | jl2^i0 | jl3^i1 | i3 | i2 | i0 | i1 | i4 | i5        (i = key row, jl = j - 16 wv)
                         // (the 32 lanes of a write group differ in jl and i3, the 16 lanes of a float4 read group in i0..i3 with
                         // jl3 = i2 ^ i3 ^ const: both land on distinct banks), then leaves as four coalesced 16-byte stores -- per
-                        // (row wave, column tile, g) 16 lanes cover 256 contiguous bytes of the backward's register image.
+                        // (row wave, column tile, g) 16 lanes cover 256 contiguous bytes of the backward's register image.  The reads are
+                        // issued here, the stores at the end of the block: their LDS latency runs under the block's MFMAs.
 #pragma unroll
                         for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -368,12 +371,10 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                                 *reinterpret_cast<float*>(ckx + ((x ^ (q << 2)) + 16 * (g & 1) + 256 * (g >> 1) + 64 * (q & 1) + 128 * (q >> 1)
                                                                  + 32 * (it & 1) + 512 * (it >> 1)) * 4) = St[it][q];
 #pragma unroll
-                        for (int wb = 0; wb < 4; ++wb) {    // lane (x, g) -> S[i = 16 wb + x][j = 16 wv + 4 (g >> 1) + 8 (g & 1) + 0..3]
-                            const v4u t = *reinterpret_cast<const v4u*>(ckx + (4 * ((g >> 1) ^ (x & 1)) + 8 * ((g & 1) ^ ((x >> 1) & 1)) + 16 * ((x >> 3) & 1)
-                                                                              + 32 * ((x >> 2) & 1) + 64 * (x & 1) + 128 * ((x >> 1) & 1) + 256 * wb) * 4);
-                            __builtin_amdgcn_raw_buffer_store_b128(t, rs_ck, (int)(st * 16384u + wb * 4096u
-                                + (((2 * (wv >> 1) + (g >> 1)) * 64 + 16 * (2 * (wv & 1) + (g & 1)) + x) * 16)), 0, 2 /* slc: streaming */);
-                        }
+                        for (int wb = 0; wb < 4; ++wb)      // lane (x, g) -> S[i = 16 wb + x][j = 16 wv + 4 (g >> 1) + 8 (g & 1) + 0..3]
+                            ckd[wb] = *reinterpret_cast<const v4u*>(ckx + (4 * ((g >> 1) ^ (x & 1)) + 8 * ((g & 1) ^ ((x >> 1) & 1)) + 16 * ((x >> 3) & 1)
+                                                                           + 32 * ((x >> 2) & 1) + 64 * (x & 1) + 128 * ((x >> 1) & 1) + 256 * wb) * 4);
+                        ck_off = (int)(st * 16384u + (((2 * (wv >> 1) + (g >> 1)) * 64 + 16 * (2 * (wv & 1) + (g & 1)) + x) * 16));
                     } else {
 #pragma unroll
                         for (int it = 0; it < 4; ++it)   // streamed: written once, read once by the backward
@@ -463,6 +464,11 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                     St[it][1] = fmaf(d16.y, St[it][1], dm.y * o[1]);
                     St[it][2] = fmaf(d16.z, St[it][2], dm.z * o[2]);
                     St[it][3] = fmaf(d16.w, St[it][3], dm.w * o[3]);
+                }
+                if (ck_off >= 0) {
+#pragma unroll
+                    for (int wb = 0; wb < 4; ++wb)
+                        __builtin_amdgcn_raw_buffer_store_b128(ckd[wb], rs_ck, ck_off + wb * 4096, 0, 2 /* slc: streaming */);
                 }
             }
             WKV6_T(ts1);

@@ -38,6 +38,7 @@
 //     hand-over carries a tag (stage index + 1) its readers poll (XT_OFF, xflag below).
 // Launches that split a (batch, head) pair over two workgroups (ScanArgs::split) stay with wkv6_chunk_bwd12.hip and its 32-token
 // checkpoints: the row and column roles cannot share LDS there.
+#include <type_traits>
 #include "wkv6_chunk.h"
 
 namespace wkv6 {
@@ -231,35 +232,78 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             asm volatile("" : "+v"(pk[0].x), "+v"(pk[0].y), "+v"(pk[1].x), "+v"(pk[1].y),
                               "+v"(pe[0].x), "+v"(pe[0].y), "+v"(pe[0].z), "+v"(pe[0].w), "+v"(pe[1].x), "+v"(pe[1].y), "+v"(pe[1].z), "+v"(pe[1].w));
     };
-    // K part of stage `stg`: decays, prefix sums, Khat hi | lo, E16, E16m8; leaves ck_, cfr, clw, cc8 for prep_r of the same stage
-    auto prep_k = [&](int stg) {
-        char* const kb = kpart(stg, pb);
-        float k[2][4], cs[2][4];
+    // One iteration of the producers: the R part of stage sr (Rhat hi | lo, fR, lw, raw r / k, E8, r.u.k -- from r and from what the
+    // K part of that stage left in ck_, cfr, clw, cc8 an iteration ago) and the K part of stage sk = sr - 1 (decays, prefix sums,
+    // Khat hi | lo, E16, E16m8; refills ck_, cfr, clw, cc8).  Either may be absent (sr / sk < 0: pipeline head and tail).  The two
+    // are written as ONE body on purpose: their dependent chains (exp -> scale -> split -> store here, exp -> butterfly -> exp ->
+    // scale -> split -> store there) are what a producer's time is made of, and only inside one basic block does the scheduler
+    // run them side by side -- as two consecutive functions the preparation took 4.7 k instead of 4.1 k cycles per stage
+    // (profiles/r04_stamps_bwd12k_v1.txt).
+    // (HASR / HASK are compile-time: a run-time `if (sk >= 0)` would cut the body into the very basic blocks it is meant to avoid;
+    // the lane-predicated stores -- r.u.k, E8, E16, E16m8 -- come last for the same reason)
+    auto prep = [&](auto HASR, auto HASK, int sr, int sk) {
+        char* const rb = rpart(HASR ? sr : 0, pb);
+        char* const kb = kpart(HASK ? sk : 0, pb);
+        float r[2][4], ko[2][4], k[2][4], cs[2][4], lwn[2][4], coef[2] = {0.f, 0.f};
+        // ---- R, first half: everything that reads the carried raw k and gw multipliers (the K part below replaces them)
+        if constexpr (HASR) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const bool valid = stg * STG + pb * BLK + 2 * tq + tt < ntok;
-            k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
-            ck_[tt] = pk[tt];
-            float lw[4];
-            if constexpr (W_RAW) {
-                lw[0] = -exp2_fast(LOG2E * bf_lo(pw[tt].x)); lw[1] = -exp2_fast(LOG2E * bf_hi(pw[tt].x));
-                lw[2] = -exp2_fast(LOG2E * bf_lo(pw[tt].y)); lw[3] = -exp2_fast(LOG2E * bf_hi(pw[tt].y));
-            } else {
-                lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
-            }
+            for (int tt = 0; tt < 2; ++tt) {
+                r[tt][0] = bf_lo(pr[tt].x); r[tt][1] = bf_hi(pr[tt].x); r[tt][2] = bf_lo(pr[tt].y); r[tt][3] = bf_hi(pr[tt].y);
+                ko[tt][0] = bf_lo(ck_[tt].x); ko[tt][1] = bf_hi(ck_[tt].x); ko[tt][2] = bf_lo(ck_[tt].y); ko[tt][3] = bf_hi(ck_[tt].y);
+                float part = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float l = valid ? fmaxf(lw[c] * LOG2E, LW_MIN2) : 0.f;   // the decay the block algebra uses, in log2 units
-                cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + l;
-                // gw multiplier: the true lw, times d_true / d_clamped where the clamp is active (the algebra yields the
-                // exact gradient of the clamped model, d_clamped * X; the true one is d_true * X)
-                clw[tt][c] = valid ? lw[c] : 0.f;
-            }
-            if (__builtin_amdgcn_ballot_w64(clw[tt][0] < LW_MIN || clw[tt][1] < LW_MIN || clw[tt][2] < LW_MIN || clw[tt][3] < LW_MIN)) {   // rare
-#pragma unroll
-                for (int c = 0; c < 4; ++c) clw[tt][c] *= exp2_fast(LOG2E * fminf(clw[tt][c] - LW_MIN, 0.f));
+                for (int c = 0; c < 4; ++c) part = fmaf(r[tt][c] * uu[c], ko[tt][c], part);
+                part += dpp_mov<DPP_XOR1>(part);
+                part += dpp_mov<DPP_XOR2>(part);
+                part += dpp_mov<DPP_SHL4>(part);
+                coef[tt] = part;
+                const int tok = 2 * tq + tt;
+                // raw r, k: only read as (token x, 4 channels) uint2 by the row waves; tokens >= 8 keep their 16-byte units swapped
+                // in pairs so that rows x and x + 8 (same bank at the 160-B stride) do not collide in that read
+                char* const rowz = rb + tok * RSB + ((ch0 * 2) ^ ((tok & 8) << 1));
+                *reinterpret_cast<uint2*>(rowz + R_R * ARR) = pr[tt];
+                *reinterpret_cast<uint2*>(rowz + R_K * ARR) = ck_[tt];
+                *reinterpret_cast<float4*>(rb + ROFF_LW + tok * FRS + ch0 * 4) = make_float4(clw[tt][0], clw[tt][1], clw[tt][2], clw[tt][3]);
             }
         }
+        // ---- K, first half: log-decays of the stage's tokens, their sums inside the lane, the gw multipliers
+        if constexpr (HASK) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const bool valid = sk * STG + pb * BLK + 2 * tq + tt < ntok;
+                k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
+                ck_[tt] = pk[tt];
+                float lw[4];
+                if constexpr (W_RAW) {
+                    lw[0] = -exp2_fast(LOG2E * bf_lo(pw[tt].x)); lw[1] = -exp2_fast(LOG2E * bf_hi(pw[tt].x));
+                    lw[2] = -exp2_fast(LOG2E * bf_lo(pw[tt].y)); lw[3] = -exp2_fast(LOG2E * bf_hi(pw[tt].y));
+                } else {
+                    lw[0] = pe[tt].x; lw[1] = pe[tt].y; lw[2] = pe[tt].z; lw[3] = pe[tt].w;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float l = valid ? fmaxf(lw[c] * LOG2E, LW_MIN2) : 0.f;   // the decay the block algebra uses, in log2 units
+                    cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + l;
+                    // gw multiplier: the true lw, times d_true / d_clamped where the clamp is active (the algebra yields the
+                    // exact gradient of the clamped model, d_clamped * X; the true one is d_true * X)
+                    lwn[tt][c] = valid ? lw[c] : 0.f;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(lwn[0][0] < LW_MIN || lwn[0][1] < LW_MIN || lwn[0][2] < LW_MIN || lwn[0][3] < LW_MIN ||
+                                            lwn[1][0] < LW_MIN || lwn[1][1] < LW_MIN || lwn[1][2] < LW_MIN || lwn[1][3] < LW_MIN)) {   // rare
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) lwn[tt][c] *= exp2_fast(LOG2E * fminf(lwn[tt][c] - LW_MIN, 0.f));
+            }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { k[tt][c] = 0.f; cs[tt][c] = 0.f; lwn[tt][c] = 0.f; }
+        }
+        // ---- one block of straight-line code: K's prefix butterfly and scaling beside R's scaling and split
         float pre[4], c8[4], c16[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -277,13 +321,23 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             pre[c] = pfx;
             c8[c] = a_;                                                  // tokens 0..7 = pairs 0..3 = the lower half's total
             c16[c] = a_ + b_;                                            // whole block
-            cc8[c] = a_;
         }
-        if (tq == 0) {
-            *reinterpret_cast<float4*>(kb + KOFF_E16 + ch0 * 4) =
-                make_float4(exp2_fast(c16[0]), exp2_fast(c16[1]), exp2_fast(c16[2]), exp2_fast(c16[3]));
-            *reinterpret_cast<float4*>(kb + KOFF_E16M8 + ch0 * 4) =
-                make_float4(exp2_fast(c16[0] - c8[0]), exp2_fast(c16[1] - c8[1]), exp2_fast(c16[2] - c8[2]), exp2_fast(c16[3] - c8[3]));
+        if constexpr (HASR) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                float rh[4], fr[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    fr[c] = exp2_fast(cfr[tt][c]);
+                    rh[c] = r[tt][c] * fr[c];
+                }
+                const int tok = 2 * tq + tt;
+                char* const row = rb + tok * RSB + ch0 * 2;
+                uint2 hi, lo;
+                split4(rh, hi, lo);
+                *reinterpret_cast<uint2*>(row + R_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + R_RL * ARR) = lo;
+                *reinterpret_cast<float4*>(rb + ROFF_FR + tok * FRS + ch0 * 4) = make_float4(fr[0], fr[1], fr[2], fr[3]);
+            }
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -292,51 +346,36 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             for (int c = 0; c < 4; ++c) {
                 const float cex = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
                 const float cin = pre[c] + cs[tt][c];
-                cfr[tt][c] = cex - c8[c];                                // fR = 2^this, formed with the R part
+                cfr[tt][c] = cex - c8[c];                                // fR = 2^this, formed with the stage's R part
+                clw[tt][c] = lwn[tt][c];
                 kh[c] = k[tt][c] * exp2_fast(c8[c] - cin);
             }
-            char* const row = kb + (2 * tq + tt) * RSB + ch0 * 2;
-            uint2 hi, lo;
-            split4(kh, hi, lo);
-            *reinterpret_cast<uint2*>(row + K_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + K_KL * ARR) = lo;
-        }
-    };
-    // R part of stage `stg` (whose K part was the last one prepared): Rhat hi | lo, fR, lw, raw r / k, E8, r.u.k
-    auto prep_r = [&](int stg) {
-        char* const rb = rpart(stg, pb);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            float r[4], k[4], rh[4], fr[4];
-            r[0] = bf_lo(pr[tt].x); r[1] = bf_hi(pr[tt].x); r[2] = bf_lo(pr[tt].y); r[3] = bf_hi(pr[tt].y);
-            k[0] = bf_lo(ck_[tt].x); k[1] = bf_hi(ck_[tt].x); k[2] = bf_lo(ck_[tt].y); k[3] = bf_hi(ck_[tt].y);
-            float part = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) part = fmaf(r[c] * uu[c], k[c], part);
-            part += dpp_mov<DPP_XOR1>(part);
-            part += dpp_mov<DPP_XOR2>(part);
-            part += dpp_mov<DPP_SHL4>(part);
-            const int tok = 2 * tq + tt;
-            if (c8i == 0) *reinterpret_cast<float*>(rb + ROFF_COEF + (half * 16 + tok) * 4) = part;
-            // raw r, k: only read as (token x, 4 channels) uint2 by the row waves; tokens >= 8 keep their 16-byte units swapped
-            // in pairs so that rows x and x + 8 (same bank at the 160-B stride) do not collide in that read
-            char* const rowz = rb + tok * RSB + ((ch0 * 2) ^ ((tok & 8) << 1));
-            *reinterpret_cast<uint2*>(rowz + R_R * ARR) = pr[tt];
-            *reinterpret_cast<uint2*>(rowz + R_K * ARR) = ck_[tt];
-            *reinterpret_cast<float4*>(rb + ROFF_LW + tok * FRS + ch0 * 4) = make_float4(clw[tt][0], clw[tt][1], clw[tt][2], clw[tt][3]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                fr[c] = exp2_fast(cfr[tt][c]);
-                rh[c] = r[c] * fr[c];
+            if constexpr (HASK) {
+                char* const row = kb + (2 * tq + tt) * RSB + ch0 * 2;
+                uint2 hi, lo;
+                split4(kh, hi, lo);
+                *reinterpret_cast<uint2*>(row + K_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + K_KL * ARR) = lo;
             }
-            char* const row = rb + tok * RSB + ch0 * 2;
-            uint2 hi, lo;
-            split4(rh, hi, lo);
-            *reinterpret_cast<uint2*>(row + R_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + R_RL * ARR) = lo;
-            *reinterpret_cast<float4*>(rb + ROFF_FR + tok * FRS + ch0 * 4) = make_float4(fr[0], fr[1], fr[2], fr[3]);
         }
-        if (tq == 0)
-            *reinterpret_cast<float4*>(rb + ROFF_E8 + ch0 * 4) =
-                make_float4(exp2_fast(cc8[0]), exp2_fast(cc8[1]), exp2_fast(cc8[2]), exp2_fast(cc8[3]));
+        if constexpr (HASR) {
+            if (c8i == 0) {
+                *reinterpret_cast<float*>(rb + ROFF_COEF + (half * 16 + 2 * tq) * 4) = coef[0];
+                *reinterpret_cast<float*>(rb + ROFF_COEF + (half * 16 + 2 * tq + 1) * 4) = coef[1];
+            }
+        }
+        if (tq == 0) {
+            if constexpr (HASR)
+                *reinterpret_cast<float4*>(rb + ROFF_E8 + ch0 * 4) =
+                    make_float4(exp2_fast(cc8[0]), exp2_fast(cc8[1]), exp2_fast(cc8[2]), exp2_fast(cc8[3]));
+            if constexpr (HASK) {
+                *reinterpret_cast<float4*>(kb + KOFF_E16 + ch0 * 4) =
+                    make_float4(exp2_fast(c16[0]), exp2_fast(c16[1]), exp2_fast(c16[2]), exp2_fast(c16[3]));
+                *reinterpret_cast<float4*>(kb + KOFF_E16M8 + ch0 * 4) =
+                    make_float4(exp2_fast(c16[0] - c8[0]), exp2_fast(c16[1] - c8[1]), exp2_fast(c16[2] - c8[2]), exp2_fast(c16[3] - c8[3]));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cc8[c] = c8[c];
     };
 
     // ---- phase-C role
@@ -400,6 +439,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         const v4u_t f = *(lds_vv4u*)(smem + off + lane * 16);
         return make_uint4(f.x, f.y, f.z, f.w);
     };
+    constexpr std::true_type yes_c{};
+    constexpr std::false_type no_c{};
     if (producer) {
         // =============== producers: R part of stage s-1 and K part of stage s-2 while stage s is consumed =====
         if (ngrp > 0) {
@@ -408,14 +449,14 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             take_kw();
             take_r();
             if (ngrp > 1) load_kw(ngrp - 2);
-            prep_k(ngrp - 1);
-            prep_r(ngrp - 1);
+            prep(no_c, yes_c, -1, ngrp - 1);                       // K part of the last stage
             if (ngrp > 1) {
                 take_kw();
                 load_r(ngrp - 2);
                 if (ngrp > 2) load_kw(ngrp - 3);
-                prep_k(ngrp - 2);
             }
+            if (ngrp > 1) prep(yes_c, yes_c, ngrp - 1, ngrp - 2);  // its R part, and the K part of the stage in front
+            else prep(yes_c, no_c, 0, -1);
         }
         __syncthreads();
         for (int grp = ngrp - 1; grp >= 0; --grp) {
@@ -434,8 +475,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     if (grp > 2) load_kw(grp - 3);
                 }
                 WKV6_T(ts2);
-                prep_r(grp - 1);
-                if (grp > 1) prep_k(grp - 2);
+                if (grp > 1) prep(yes_c, yes_c, grp - 1, grp - 2);
+                else prep(yes_c, no_c, 0, -1);
             }
             WKV6_T(ts3);
             __syncthreads();

@@ -72,7 +72,7 @@ if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wav
     bwd()
     torch.cuda.synchronize()
     d = buf.view(B * H, 16, 8).double().mean(0)         # average over workgroups: [wave][phase]
-    if os.environ.get("WKV6_BWD", "64") != "12":
+    if os.environ.get("WKV6_BWD", "") == "64":
         nc = (T + 63) // 64
         print("two-level backward, cycles per 64-token chunk and wave (avg over workgroups): [phase A, barrier, phase B, barrier, phase C, barrier]")
         for wv in range(16):
@@ -80,7 +80,7 @@ if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wav
         sys.exit(0)
     ns = (T + 31) // 32
     print("backward, cycles per 32-token stage and wave (avg over workgroups):")
-    print("  row waves 0-3  = [ckpt load, rebuild, pre-phase, chain, barrier]")
+    print("  row waves 0-3  = [tiles + ckpt wait, rebuild, pre-phase, chain, barrier]")
     print("  col waves 4-7  = [pre-phase, chain, barrier]")
     print("  producers 8-11 = [load wait, prep, load issue, barrier]")
     for wv in range(12):
