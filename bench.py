@@ -11,7 +11,7 @@ reported value is the whole-job rate: N * tokens / max-over-ranks time.  Rank 0 
 
 Algorithmic bytes: forward reads r,k,v,w and writes y = 10 B per token-channel, backward
 reads r,k,v,w,gy and writes gr,gk,gv,gw = 18 B; 28 B per token-channel for the step.  The forward also writes, and
-the backward reads, one fp32 64x64 state checkpoint per 32 tokens (8 B per token-channel each way) -- real traffic
+the backward reads, one fp32 64x64 state checkpoint per 64 tokens (4 B per token-channel each way) -- real traffic
 (reported in roofline.traffic) that is NOT counted in the algorithmic figure.
 """
 import argparse
@@ -30,7 +30,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI3
 FWD_BYTES, BWD_BYTES = 10, 18   # per token-channel
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_final_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_final_pmc.json")
 
 
 def pmc_from_file():
@@ -48,8 +48,8 @@ def add_counter_rows(rows, acc):
     per_dispatch = {}
     for row in rows:
         kn = row["Kernel_Name"]
-        key = "chunk_bwd12_kernel" if "chunk_bwd12" in kn else "chunk_bwd64_kernel" if "chunk_bwd64" in kn else \
-            "chunk_fwd_kernel" if "chunk_fwd_kernel" in kn else None
+        key = "chunk_bwd12k_kernel" if "chunk_bwd12k" in kn else "chunk_bwd12_kernel" if "chunk_bwd12" in kn else \
+            "chunk_bwd64_kernel" if "chunk_bwd64" in kn else "chunk_fwd_kernel" if "chunk_fwd_kernel" in kn else None
         if key:
             id_ = (key, row["Counter_Name"], row["Dispatch_Id"])
             per_dispatch[id_] = per_dispatch.get(id_, 0.0) + float(row["Counter_Value"])
@@ -80,7 +80,7 @@ def pmc_live(timeout_s=75):
     import subprocess
     import tempfile
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(prof):
+    if not os.path.exists(prof) or under_profiler():
         return {}
     acc = {}
     tmp = tempfile.mkdtemp(prefix="wkv6_bench_pmc_", dir="/tmp")
@@ -90,8 +90,20 @@ def pmc_live(timeout_s=75):
             out = os.path.join(tmp, f"g{i}")
             cmd = [prof, "--kernel-trace", "--pmc", *grp, "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
-            if r.returncode != 0:
+            # own session: on a timeout the whole group goes (rocprofv3 AND the profiled python under it), so that no GPU holder
+            # is left running beside the timed section
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = child.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                child.wait()
+                return {}
+            if rc != 0:
                 return {}
             for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
                 with open(f) as fh:
@@ -101,6 +113,12 @@ def pmc_live(timeout_s=75):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return reduce_counters(acc)
+
+
+def under_profiler():
+    """Is this process itself running under rocprofv3 / another preloaded tool?  Then no second profiler is started beneath it
+    (the children would inherit the preload environment)."""
+    return any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
 def pmc_child():
@@ -255,10 +273,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    # the profiled child runs come first, while this process has not initialised the GPU (device_count() does not): no fork + exec
-    # from a process that holds a HIP context
+    # the profiled child runs come first, before this process makes ANY torch.cuda call (no fork + exec from a process that holds a
+    # HIP context; the presence of a GPU is read from the device node, not from the runtime)
     pmc, pmc_source = {}, None
-    if args.workload == "wkv6" and rank == 0 and args.traffic != "none" and torch.cuda.device_count() > 0:
+    if args.workload == "wkv6" and rank == 0 and args.traffic != "none" and os.path.exists("/dev/kfd"):
         if args.traffic == "live" and world == 1:
             pmc, pmc_source = pmc_live(), "rocprofv3 --pmc child runs of this invocation"
         if not pmc:
@@ -369,7 +387,8 @@ def main():
         units = tokens * C                                    # token-channels per step per GPU
         dom_name, dom_ms, dom_b = ("backward", bwd_ms, BWD_BYTES) if bwd_ms >= fwd_ms else ("forward", fwd_ms, FWD_BYTES)
         dom_kernel = "chunk_fwd_kernel" if dom_name == "forward" else \
-            "chunk_bwd64_kernel" if os.environ.get("WKV6_BWD") == "64" else "chunk_bwd12_kernel"
+            {"64": "chunk_bwd64_kernel", "32": "chunk_bwd12_kernel", "12": "chunk_bwd12_kernel"}.get(os.environ.get("WKV6_BWD", ""),
+                                                                                                  "chunk_bwd12k_kernel")
         ach = units * dom_b / (dom_ms * 1e-3) / 1e9
         step_bytes = FWD_BYTES if args.workload == "prefill" else FWD_BYTES + BWD_BYTES
         step_ach = units * step_bytes / ((fwd_ms + bwd_ms) * 1e-3) / 1e9

@@ -68,12 +68,15 @@ int wkv6infctx_cuda_backward(int B, int T, int C, int H, const void* r, const vo
                              const void* w, const void* u, const void* s, const void* gy, void* gr,
                              void* gk, void* gv, void* gw, void* gu, void* gs, void* stream);
 
-/* ---- rwkv6 (stateful forward-only inference): replaces cuda_forward_bf16 / cuda_forward_fp32 of
+/* ---- rwkv6 (stateful forward-only inference): replaces cuda_forward_bf16 / cuda_forward_fp16 / cuda_forward_fp32 of
  * cuda/rwkv6_op.cpp:8-10 (cuda/rwkv6.cu:8-87).  `w` is the fp32 DECAY exp(-exp(w_raw)) (src/model_run.py:64),
  * `state` is fp32 [B,H,N,N] (value-major, like s above; [H,N,N] for B = 1 as the reference uses it) and is updated
  * in place.  The reference indexes the state without the batch (`wrong if B > 1`, cuda/rwkv6.cu:17); here every
- * batch row has its own state.  (The fp16 flavour of the reference is not provided.) */
+ * batch row has its own state.  The fp16 flavour takes r, k, v, u, y in IEEE half: inputs are widened to fp32 in the
+ * kernel (exact), the arithmetic and the state are fp32 and y is rounded to nearest even, as cuda/rwkv6.cu:8-71. */
 int rwkv6_cuda_forward_bf16(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,
+                            const float* w, const void* u, void* y, void* stream);
+int rwkv6_cuda_forward_fp16(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,
                             const float* w, const void* u, void* y, void* stream);
 int rwkv6_cuda_forward_fp32(int B, int T, int C, int H, float* state, const float* r, const float* k, const float* v,
                             const float* w, const float* u, float* y, void* stream);
@@ -126,10 +129,10 @@ int wkv6_backward_ex(int B, int T, int C, int H, const void* r, const void* k, c
                      void* gk, void* gv, void* gw, void* gu, void* gs, void* workspace,
                      size_t workspace_bytes, unsigned flags, void* stream);
 /* lens: int32 [B] device array, number of leading tokens both scans cover (NULL: derive from mask).
- * workspace: wkv6bi_workspace_bytes() bytes (NULL: stream-ordered allocation for the duration of the call), or only
+ * workspace: at least wkv6bi_workspace_bytes() bytes (NULL: stream-ordered allocation for the duration of the call), or EXACTLY
  * wkv6bi_kept_bytes() bytes -- the part that must live from a WKV6_BI_KEEP_CKPT forward to its backward (row lengths and the two
  * scans' checkpoints); the fp32 [B,T,C] side buffers (one in the forward, four in the backward) are then stream-ordered scratch
- * of the call. */
+ * of the call.  Any other size is refused with WKV6_EWORKSPACE. */
 int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
                       const void* k, const void* v, const void* w, const void* u, void* y,
                       void* workspace, size_t workspace_bytes, unsigned flags, void* stream);

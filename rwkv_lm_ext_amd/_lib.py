@@ -33,6 +33,7 @@ SIGNATURES = {
     "wkv6infctx_cuda_forward": (_I, [_I] * 4 + [_VP] * 8),
     "wkv6infctx_cuda_backward": (_I, [_I] * 4 + [_VP] * 14),
     "rwkv6_cuda_forward_bf16": (_I, [_I] * 4 + [_VP] * 8),
+    "rwkv6_cuda_forward_fp16": (_I, [_I] * 4 + [_VP] * 8),
     "rwkv6_cuda_forward_fp32": (_I, [_I] * 4 + [_VP] * 8),
     "wkv6_backward_workspace_bytes": (_SZ, [_I] * 4),
     "wkv6bi_workspace_bytes": (_SZ, [_I] * 4),

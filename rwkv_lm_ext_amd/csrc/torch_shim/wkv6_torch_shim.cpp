@@ -162,17 +162,20 @@ void rwkv6_forward_fp32(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& stat
                                w.data_ptr<float>(), u.data_ptr<float>(), y.data_ptr<float>(), stream_of(r)), "rwkv6 forward_fp32");
 }
 
-// cuda/rwkv6_op.cpp:16-19: the reference's fp16 kernel widens every input to fp32, computes in fp32 and rounds y to fp16
-// (cuda/rwkv6.cu:8-71); fp16 -> fp32 is exact, so the fp32 kernel on widened copies, rounded once, gives the same values
+// cuda/rwkv6_op.cpp:16-19: r, k, v, u, y in fp16; the kernel widens the inputs to fp32 (exact), computes and carries the state in
+// fp32 and rounds y to fp16 once (cuda/rwkv6.cu:8-71)
 void rwkv6_forward_fp16(int64_t B, int64_t T, int64_t C, int64_t H, Tensor& state, Tensor& r, Tensor& k, Tensor& v, Tensor& w,
                         Tensor& u, Tensor& y)
 {
     constexpr auto F16 = at::kHalf;
+    need_sizes(B, T, C, H);
+    need(state, "state", F32, r);
     need_btc(r, "r", B, T, C, F16, r); need_btc(k, "k", B, T, C, F16, r); need_btc(v, "v", B, T, C, F16, r);
-    need(u, "u", F16, r); need_btc(y, "y", B, T, C, F16, r);
-    Tensor r32 = r.to(F32), k32 = k.to(F32), v32 = v.to(F32), u32 = u.to(F32).contiguous(), y32 = at::empty_like(r32);
-    rwkv6_forward_fp32(B, T, C, H, state, r32, k32, v32, w, u32, y32);
-    y.copy_(y32);
+    need_btc(w, "w", B, T, C, F32, r); need(u, "u", F16, r); need_btc(y, "y", B, T, C, F16, r);
+    TORCH_CHECK(state.numel() == B * H * 64 * 64, "state must be [B,H,N,N] ([H,N,N] for B = 1)");
+    const DeviceGuard guard(r.device());
+    ok(rwkv6_cuda_forward_fp16(B, T, C, H, state.data_ptr<float>(), r.data_ptr(), k.data_ptr(), v.data_ptr(), w.data_ptr<float>(),
+                               u.data_ptr(), y.data_ptr(), stream_of(r)), "rwkv6 forward_fp16");
 }
 
 }  // namespace

@@ -206,7 +206,7 @@ hipError_t chunk_forward(const ScanArgs& a, hipStream_t st)
 // forward dispatch: chunked MFMA kernel for bf16 I/O unless the caller forces the exact scan
 hipError_t run_fwd(const ScanArgs& a, unsigned flags, hipStream_t st)
 {
-    if ((flags & WKV6_IO_F32) || (flags & WKV6_ALGO_SCAN)) return launch_scan_fwd(a, flags & WKV6_IO_F32, st);
+    if ((flags & WKV6_IO_F32) || (flags & WKV6_ALGO_SCAN)) return launch_scan_fwd(a, (flags & WKV6_IO_F32) ? IO_F32 : IO_BF16, st);
     return chunk_forward(a, st);
 }
 
@@ -287,8 +287,10 @@ size_t wkv6bi_workspace_bytes(int B, int T, int C, int H)
     return wkv6bi_kept_bytes(B, T, C, H) + 4 * bi_side_bytes(B, T, C);
 }
 // workspace == NULL: everything is stream-ordered scratch for the call; >= wkv6bi_workspace_bytes(): everything is carved from
-// it; >= wkv6bi_kept_bytes(): the caller keeps only the part that must survive until the backward and the `nside` fp32 side
-// buffers this call needs are stream-ordered scratch.  Returns false when the workspace is too small or the allocation fails.
+// it; EXACTLY wkv6bi_kept_bytes(): the caller keeps only the part that must survive until the backward and the `nside` fp32 side
+// buffers this call needs are stream-ordered scratch (an explicit choice: any other short size is an undersized buffer and is
+// refused, so that a caller sized for an older layout gets WKV6_EWORKSPACE instead of hidden allocations).  Returns false when
+// the workspace is refused or the allocation fails.
 static bool bi_workspace(void* workspace, size_t workspace_bytes, int nside, int B, int T, int C, int H, hipStream_t st,
                          StreamScratch& scratch, BiWorkspace& ws)
 {
@@ -299,7 +301,7 @@ static bool bi_workspace(void* workspace, size_t workspace_bytes, int nside, int
         ws = bi_carve(workspace, nullptr, B, T, C, H);
     } else if (workspace_bytes >= full) {
         ws = bi_carve(workspace, nullptr, B, T, C, H);
-    } else if (workspace_bytes >= kept) {
+    } else if (workspace_bytes == kept) {
         void* const side = scratch.get((size_t)nside * bi_side_bytes(B, T, C), st);
         if (!side) return false;
         ws = bi_carve(workspace, side, B, T, C, H);
@@ -396,7 +398,7 @@ int wkv6_forward_rev_ex(int B, int T, int C, int H, const void* r, const void* k
     a.rev_n = rev_n;
     a.rev_mask = rev_mask;
     if (flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN))        // exact scan kernels (fp32 I/O, or forced): same index maps, no checkpoints
-        return to_rc(launch_scan_fwd(a, flags & WKV6_IO_F32, (hipStream_t)stream));
+        return to_rc(launch_scan_fwd(a, (flags & WKV6_IO_F32) ? IO_F32 : IO_BF16, (hipStream_t)stream));
     a.ckpt = reinterpret_cast<float*>(ckpt);
     ckpt_note(ckpt, a);
     return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
@@ -596,7 +598,7 @@ int wkv6infctx_cuda_backward(int B, int T, int C, int H, const void* r, const vo
 }
 
 static int rwkv6_infer(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,
-                       const float* w, const void* u, void* y, bool f32, void* stream)
+                       const float* w, const void* u, void* y, int io, void* stream)
 {
     if (int rc = check_shape(B, T, C, H)) return rc;
     if (!state || !r || !k || !v || !w || !u || !y) return WKV6_ENULL;
@@ -607,19 +609,24 @@ static int rwkv6_infer(int B, int T, int C, int H, float* state, const void* r, 
     a.s0_bstride = (long)H * HEAD * HEAD;
     a.y = y;
     // prefill-sized calls in bf16 go through the chunked MFMA kernel (log of the given decay, fp32 state I/O); decode
-    // (a few tokens) and fp32 I/O use the exact scan
-    if (!f32 && T >= 32) return to_rc(chunk_forward(a, (hipStream_t)stream));
-    return to_rc(launch_scan_fwd(a, f32, (hipStream_t)stream));
+    // (a few tokens), fp32 I/O and fp16 I/O (r, k, v are not exact in bf16) use the exact scan
+    if (io == IO_BF16 && T >= 32) return to_rc(chunk_forward(a, (hipStream_t)stream));
+    return to_rc(launch_scan_fwd(a, io, (hipStream_t)stream));
 }
 int rwkv6_cuda_forward_bf16(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,
                             const float* w, const void* u, void* y, void* stream)
 {
-    return rwkv6_infer(B, T, C, H, state, r, k, v, w, u, y, false, stream);
+    return rwkv6_infer(B, T, C, H, state, r, k, v, w, u, y, IO_BF16, stream);
+}
+int rwkv6_cuda_forward_fp16(int B, int T, int C, int H, float* state, const void* r, const void* k, const void* v,
+                            const float* w, const void* u, void* y, void* stream)
+{
+    return rwkv6_infer(B, T, C, H, state, r, k, v, w, u, y, IO_F16, stream);
 }
 int rwkv6_cuda_forward_fp32(int B, int T, int C, int H, float* state, const float* r, const float* k, const float* v,
                             const float* w, const float* u, float* y, void* stream)
 {
-    return rwkv6_infer(B, T, C, H, state, r, k, v, w, u, y, true, stream);
+    return rwkv6_infer(B, T, C, H, state, r, k, v, w, u, y, IO_F32, stream);
 }
 
 // Device self-test: (1) the cross-lane primitives, (2) the chunked MFMA kernels against the exact scan kernels on a

@@ -8,6 +8,7 @@ namespace wkv6 {
 constexpr int HEAD = 64;             // head size N (= _N_ of the reference build, src/model.py:189)
 
 typedef unsigned short bf16_t;       // raw bfloat16 bits
+typedef _Float16 f16_t;              // IEEE half (inference kernel with fp16 I/O: cuda/rwkv6_op.cpp:9, 16-19)
 
 __device__ __forceinline__ float bf_lo(uint32_t x) { return __uint_as_float(x << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t x) { return __uint_as_float(x & 0xffff0000u); }
@@ -58,6 +59,19 @@ template <> struct io4<bf16_t> {
     {
         uint2 raw; raw.x = pack_bf2(v[0], v[1]); raw.y = pack_bf2(v[2], v[3]);
         *reinterpret_cast<uint2*>(p) = raw;
+    }
+};
+template <> struct io4<f16_t> {      // widened to fp32 on load (exact), rounded to nearest even on store, as cuda/rwkv6.cu:8-71
+    typedef f16_t h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void load(const f16_t* p, float (&o)[4])
+    {
+        const h4 raw = *reinterpret_cast<const h4*>(p);
+        o[0] = (float)raw[0]; o[1] = (float)raw[1]; o[2] = (float)raw[2]; o[3] = (float)raw[3];
+    }
+    static __device__ __forceinline__ void store(f16_t* p, const float (&v)[4])
+    {
+        const h4 raw = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+        *reinterpret_cast<h4*>(p) = raw;
     }
 };
 template <> struct io4<float> {

@@ -112,7 +112,8 @@ __device__ __forceinline__ RevMap make_revmap(const ScanArgs& a, int b, int ntok
     return RevMap{0, 0u};
 }
 
-hipError_t launch_scan_fwd(const ScanArgs& a, bool io_f32, hipStream_t st);
+enum { IO_BF16 = 0, IO_F32 = 1, IO_F16 = 2 };   // I/O element type of the scan forward (fp16: inference entry point only)
+hipError_t launch_scan_fwd(const ScanArgs& a, int io, hipStream_t st);
 hipError_t launch_scan_bwd(const ScanArgs& a, bool io_f32, hipStream_t st);
 hipError_t launch_selftest(int* result, hipStream_t st);
 // chunked MFMA forward (bf16 I/O only), wkv6_chunk.hip

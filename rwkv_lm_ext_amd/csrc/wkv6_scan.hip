@@ -21,6 +21,19 @@ template <> struct ion<bf16_t, 2> {
         *reinterpret_cast<uint32_t*>(p) = pack_bf2(v[0], v[1]);
     }
 };
+template <> struct ion<f16_t, 2> {
+    typedef f16_t h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ void load(const f16_t* p, float (&o)[2])
+    {
+        const h2 raw = *reinterpret_cast<const h2*>(p);
+        o[0] = (float)raw[0]; o[1] = (float)raw[1];
+    }
+    static __device__ __forceinline__ void store(f16_t* p, const float (&v)[2])
+    {
+        const h2 raw = {(f16_t)v[0], (f16_t)v[1]};
+        *reinterpret_cast<h2*>(p) = raw;
+    }
+};
 template <> struct ion<float, 2> {
     static __device__ __forceinline__ void load(const float* p, float (&o)[2])
     {
@@ -724,11 +737,12 @@ constexpr int NWAVES = 8;
 
 }  // namespace
 
-hipError_t launch_scan_fwd(const ScanArgs& a, bool io_f32, hipStream_t st)
+hipError_t launch_scan_fwd(const ScanArgs& a, int io, hipStream_t st)
 {
     constexpr size_t lds = (2 * 4 * TB * ROW + 64 + 2 * TB * ROW) * sizeof(float);
     const dim3 grid(a.B * a.H), block(NWAVES * 64);
-    if (io_f32) hipLaunchKernelGGL((scan_fwd_kernel<float, NWAVES>), grid, block, lds, st, a);
+    if (io == IO_F32) hipLaunchKernelGGL((scan_fwd_kernel<float, NWAVES>), grid, block, lds, st, a);
+    else if (io == IO_F16) hipLaunchKernelGGL((scan_fwd_kernel<f16_t, NWAVES>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((scan_fwd_kernel<bf16_t, NWAVES>), grid, block, lds, st, a);
     return hipGetLastError();
 }

@@ -127,7 +127,7 @@ class WKV_6_PAIR(torch.autograd.Function):
             sets = [dict(r=r0, k=k0, v=v0, w=w0, gy=gy0.contiguous(), ckpt=ctx.ckpts[0]),
                     dict(r=r1, k=k1, v=v1, w=w1, gy=gy1.contiguous(), ckpt=ctx.ckpts[1], rev_n=rev_n, rev_mask=ctx.rev_mask)]
             g0, g1 = wkv6_op.backward_pair_ex(ctx.H, u, sets)
-            ctx.ckpts = None
+            ctx.ckpts = [None, None]                   # (a second backward through this node, retain_graph=True, runs self-contained)
             gu = _sum_bf16(g0[4], shape) + _sum_bf16(g1[4], shape)     # as autograd adds the two calls' bf16 gu
             return (None, None, None, None, *g0[:4], *g1[:4], gu, None, None)
 

@@ -168,7 +168,9 @@ class _Rwkv6:
         dev = _check_tensors(B, T, C, H, dict(state=(state, sshape, torch.float32), r=(r, btc, io), k=(k, btc, io),
                                               v=(v, btc, io), w=(w, btc, torch.float32), u=(u, None, io), y=(y, btc, io)),
                              dtype=io)
-        fn = _lib.load().rwkv6_cuda_forward_bf16 if io == torch.bfloat16 else _lib.load().rwkv6_cuda_forward_fp32
+        lib = _lib.load()
+        fn = {torch.bfloat16: lib.rwkv6_cuda_forward_bf16, torch.float16: lib.rwkv6_cuda_forward_fp16,
+              torch.float32: lib.rwkv6_cuda_forward_fp32}[io]
         with torch.cuda.device(dev):
             rc = fn(B, T, C, H, _ptr(state), _ptr(r), _ptr(k), _ptr(v), _ptr(w), _ptr(u), _ptr(y), _stream_ptr())
         _lib.check(rc, "rwkv6 forward")
@@ -183,16 +185,9 @@ class _Rwkv6:
 
     @staticmethod
     def forward_fp16(B, T, C, H, state, r, k, v, w, u, y):
-        """cuda/rwkv6_op.cpp:16-19.  The reference's fp16 kernel widens every input to fp32, computes in fp32 and rounds y
-        to fp16 (cuda/rwkv6.cu:8-71); fp16 -> fp32 is exact, so running the fp32 kernel on widened copies and rounding its
-        output once gives the same values."""
-        for n, t in (("r", r), ("k", k), ("v", v), ("u", u), ("y", y)):
-            if not (isinstance(t, torch.Tensor) and t.dtype == torch.float16 and t.is_cuda):
-                raise RuntimeError(f"{n} must be a float16 GPU tensor")
-        y32 = torch.empty((B, T, C), device=y.device, dtype=torch.float32)
-        _Rwkv6._call(B, T, C, H, state, r.float().contiguous(), k.float().contiguous(), v.float().contiguous(), w,
-                     u.float().contiguous(), y32, torch.float32)
-        y.copy_(y32)
+        """cuda/rwkv6_op.cpp:16-19: r, k, v, u, y in fp16; the kernel widens the inputs to fp32 (exact), computes and carries the
+        state in fp32 and rounds y to fp16 once (cuda/rwkv6.cu:8-71)."""
+        _Rwkv6._call(B, T, C, H, state, r, k, v, w, u, y, torch.float16)
 
 
 rwkv6 = _Rwkv6
@@ -426,14 +421,22 @@ def bi_new_kept(B, T, C, H, device):
     return torch.empty(_lib.load().wkv6bi_kept_bytes(B, T, C, H), dtype=torch.uint8, device=device)
 
 
-def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None, ws=None):
+def _mask_or_lens(mask, lens, B, T):
+    """wkv6bi_*_ex take the reference's int32 mask [B,T] (row length = 1 + index of its first zero) or, instead, the row lengths
+    themselves as int32 [B] (0 .. T): exactly one of the two."""
+    if (mask is None) == (lens is None):
+        raise RuntimeError("pass either mask or lens")
+    return {"mask": (mask, (B, T), torch.int32)} if lens is None else {"lens": (lens, (B,), torch.int32)}
+
+
+def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None, ws=None, lens=None):
     """ws: a bi_new_workspace() buffer the caller keeps for bi_backward_ex(..., ws=ws): the forward then stores the state
-    checkpoints of both scans in it and the backward skips its two state passes."""
+    checkpoints of both scans in it and the backward skips its two state passes.  lens: row lengths instead of the mask."""
     B, T, C = r.shape
     io = r.dtype
     btc = (B, T, C)
     wdt = torch.float32 if w_is_ew else io
-    named = dict(mask=(mask, (B, T), torch.int32), r=(r, btc, io), k=(k, btc, io), v=(v, btc, io),
+    named = dict(**_mask_or_lens(mask, lens, B, T), r=(r, btc, io), k=(k, btc, io), v=(v, btc, io),
                  w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io))
     flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
     flags |= _lib.ALGO_SCAN if algo == "scan" else 0
@@ -444,19 +447,19 @@ def bi_forward_ex(mask, r, k, v, w, u, H, w_is_ew=False, algo=None, ws=None):
     else:
         ws = bi_new_workspace(B, T, C, H, dev)
     with torch.cuda.device(dev):
-        rc = _lib.load().wkv6bi_forward_ex(B, T, C, H, _ptr(mask), None, _ptr(r), _ptr(k), _ptr(v), _ptr(w),
+        rc = _lib.load().wkv6bi_forward_ex(B, T, C, H, _ptr(mask), _ptr(lens), _ptr(r), _ptr(k), _ptr(v), _ptr(w),
                                            _ptr(u), _ptr(y), _ptr(ws), ws.numel(), flags, _stream_ptr())
     _lib.check(rc, "wkv6_bi forward_ex")
     return y
 
 
-def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False, algo=None, ws=None):
+def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False, algo=None, ws=None, lens=None):
     """ws: the workspace a preceding bi_forward_ex(..., ws=ws) on the same inputs filled (checkpoints valid)."""
     B, T, C = r.shape
     io = r.dtype
     btc = (B, T, C)
     wdt = torch.float32 if w_is_ew else io
-    named = dict(mask=(mask, (B, T), torch.int32), r=(r, btc, io), k=(k, btc, io), v=(v, btc, io),
+    named = dict(**_mask_or_lens(mask, lens, B, T), r=(r, btc, io), k=(k, btc, io), v=(v, btc, io),
                  w=(w, btc, wdt), u=(u, (H, HEAD_SIZE), io), gy=(gy, btc, io))
     flags = (_lib.W_EW_F32 if w_is_ew else _lib.W_RAW) | (_lib.IO_F32 if io == torch.float32 else 0)
     flags |= _lib.ALGO_SCAN if algo == "scan" else 0
@@ -469,7 +472,7 @@ def bi_backward_ex(mask, r, k, v, w, u, gy, H, w_is_ew=False, algo=None, ws=None
     elif ws is None:
         ws = bi_new_workspace(B, T, C, H, dev)
     with torch.cuda.device(dev):
-        rc = _lib.load().wkv6bi_backward_ex(B, T, C, H, _ptr(mask), None, _ptr(r), _ptr(k), _ptr(v), _ptr(w),
+        rc = _lib.load().wkv6bi_backward_ex(B, T, C, H, _ptr(mask), _ptr(lens), _ptr(r), _ptr(k), _ptr(v), _ptr(w),
                                             _ptr(u), _ptr(gy), _ptr(gr), _ptr(gk), _ptr(gv), _ptr(gw), _ptr(gu),
                                             _ptr(ws), ws.numel(), flags, _stream_ptr())
     _lib.check(rc, "wkv6_bi backward_ex")

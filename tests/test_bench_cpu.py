@@ -15,20 +15,21 @@ def test_algorithmic_bytes():
 
 def test_committed_pmc_figures_are_consistent():
     pmc = bench.pmc_from_file()
-    bwd, fwd = pmc["chunk_bwd12_kernel"]["hbm_bytes"], pmc["chunk_fwd_kernel"]["hbm_bytes"]
+    bwd, fwd = pmc["chunk_bwd12k_kernel"]["hbm_bytes"], pmc["chunk_fwd_kernel"]["hbm_bytes"]
     units = 8 * 4096 * 2048
-    ckpt = units * 8                                   # one fp32 64x64 state per 32 tokens and head = 8 B per token-channel
-    # measured traffic = algorithmic bytes + checkpoints, within 1 % (no re-reads)
-    assert abs(bwd - (units * 18 + ckpt)) <= 0.01 * bwd
-    assert abs(fwd - (units * 10 + ckpt)) <= 0.01 * fwd
-    for k in ("chunk_bwd12_kernel", "chunk_fwd_kernel"):
+    ckpt = units * 4                                   # one fp32 64x64 state per 64 tokens and head = 4 B per token-channel
+    # measured traffic = algorithmic bytes + checkpoints, within 2 % (no re-reads from HBM: the second stage of a 64-token pair
+    # takes its checkpoint from the L2)
+    assert abs(bwd - (units * 18 + ckpt)) <= 0.02 * bwd
+    assert abs(fwd - (units * 10 + ckpt)) <= 0.02 * fwd
+    for k in ("chunk_bwd12k_kernel", "chunk_fwd_kernel"):
         assert 0.2 < bench.valu_busy_of(pmc[k]["counters"]) < 1.0
     assert bench.valu_busy_of({}) is None
 
 
 def test_committed_bench_lines_carry_the_contract_fields():
     root = os.path.dirname(os.path.abspath(bench.__file__))
-    for name in ("r03_bench_final.json", "r03_bench_bi.json", "r03_bench_infctx.json"):
+    for name in ("r04_bench_final.json", "r04_bench_bi.json", "r04_bench_infctx.json"):
         with open(os.path.join(root, "profiles", name)) as f:
             d = json.loads(f.read())
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",

@@ -136,6 +136,25 @@ def test_pair_launch_is_the_two_calls_bit_for_bit(op, mask_name, B, T, H):
         op.backward_pair_ex(H, u, sets2)
 
 
+def test_pair_autograd_node_survives_a_second_backward(op):
+    """WKV_6_PAIR drops its checkpoints after the first backward; a second backward through the same node (retain_graph=True) must
+    take the self-contained route (each problem's own state pass) and give the same gradients."""
+    from rwkv_lm_ext_amd.wkv import WKV_6_PAIR
+    B, T, H = 2, 100, 2
+    C = 64 * H
+    leaves = [rnd(B, T, C, scale=0.5, seed=40 + i).requires_grad_(True) for i in range(3)]
+    w = (rnd(B, T, C, scale=0.7, seed=44).float() - 2.0).to(bf).requires_grad_(True)
+    u = rnd(H, 64, scale=0.3, seed=45).requires_grad_(True)
+    rev_n = torch.tensor([T, 37], dtype=torch.int32, device="cuda")
+    r, k, v = leaves
+    y0, y1 = WKV_6_PAIR.apply(B, T, C, H, r, k, v, w, r, k, v, w, u, rev_n, op.REV_K | op.REV_V | op.REV_Y)
+    loss = (y0.float() * 0.5 + y1.float()).sum()
+    first = torch.autograd.grad(loss, [r, k, v, w, u], retain_graph=True)
+    second = torch.autograd.grad(loss, [r, k, v, w, u])
+    for a_, b_ in zip(first, second):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("comp", ["B", "C"])
 def test_compositions_with_pair_launch_equal_two_launches(comp):
     """Tmix_x060.forward_bi_b / forward_bi_c with pair_launch on and off: same outputs and parameter gradients, bit for bit."""

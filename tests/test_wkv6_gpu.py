@@ -640,3 +640,26 @@ def test_rwkv6_stateful_inference_kernel(ops, oracle, io):
     y2, _ = RUN_RWKV_6(2, 3, C, H, st2, *(t[:, Tp:].contiguous() for t in d[:4]), d[4])
     check(torch.cat([y1, y2], 1), yo, io, "rwkv6 prefill + decode y")
     assert max_norm_err(host(st2), so) <= (F32_TOL if io == torch.float32 else 2e-4)   # chunked path: split-bf16 products
+
+
+def test_rwkv6_fp16_symbol_widens_in_the_kernel(ops, oracle):
+    """rwkv6_cuda_forward_fp16 (cuda/rwkv6_op.cpp:9, 16-19): fp16 r, k, v, u, y with the fp32 state and decay of the other flavours;
+    inputs are widened in the kernel (no fp32 copies on the host side), y is rounded to fp16 once.  Checked against the oracle on
+    the fp16-rounded inputs, and bit for bit against the fp32 flavour rounded to fp16."""
+    B, T, H = 2, 41, 2
+    C = H * 64
+    h16 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch.float16)
+    r, k, v, w, u, _ = rand_inputs(77, B, T, H)
+    r16, k16, v16, u16 = (h16(t) for t in (r, k, v, u))
+    g = torch.Generator().manual_seed(78)
+    s0 = (torch.randn(B, H, 64, 64, generator=g) * 0.5).numpy()
+    yo, so = oracle.forward(r16.float().numpy(), k16.float().numpy(), v16.float().numpy(), w, u16.float().numpy(), s0, return_state=True)
+    decay = torch.exp(-torch.exp(torch.from_numpy(w).float())).cuda().contiguous()       # src/model_run.py:64
+    st16, st32 = dev(s0, torch.float32), dev(s0, torch.float32)
+    y16 = torch.empty(B, T, C, dtype=torch.float16, device="cuda")
+    ops.rwkv6.forward_fp16(B, T, C, H, st16, r16.cuda(), k16.cuda(), v16.cuda(), decay, u16.cuda(), y16)
+    assert max_norm_err(host(y16), yo) <= 1e-3                        # fp16 output rounding: 2^-11 relative
+    assert max_norm_err(host(st16), so) <= F32_TOL
+    y32 = torch.empty(B, T, C, dtype=torch.float32, device="cuda")
+    ops.rwkv6.forward_fp32(B, T, C, H, st32, r16.cuda().float(), k16.cuda().float(), v16.cuda().float(), decay, u16.cuda().float(), y32)
+    assert torch.equal(y16, y32.to(torch.float16)) and torch.equal(st16, st32)
