@@ -364,6 +364,10 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                         // jl3 = i2 ^ i3 ^ const: both land on distinct banks), then leaves as four coalesced 16-byte stores -- per
                         // (row wave, column tile, g) 16 lanes cover 256 contiguous bytes of the backward's register image.  The reads are
                         // issued here, the stores at the end of the block: their LDS latency runs under the block's MFMAs.
+#ifdef WKV6_EXP_CK_NOLDS                                         // timing-only experiment: the row-order store pattern without the LDS transposition (wrong data)
+#pragma unroll
+                        for (int wb = 0; wb < 4; ++wb) ckd[wb] = __builtin_bit_cast(v4u, St[wb]);
+#else
 #pragma unroll
                         for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -374,6 +378,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                         for (int wb = 0; wb < 4; ++wb)      // lane (x, g) -> S[i = 16 wb + x][j = 16 wv + 4 (g >> 1) + 8 (g & 1) + 0..3]
                             ckd[wb] = *reinterpret_cast<const v4u*>(ckx + (4 * ((g >> 1) ^ (x & 1)) + 8 * ((g & 1) ^ ((x >> 1) & 1)) + 16 * ((x >> 3) & 1)
                                                                            + 32 * ((x >> 2) & 1) + 64 * (x & 1) + 128 * ((x >> 1) & 1) + 256 * wb) * 4);
+#endif
                         ck_off = (int)(st * 16384u + (((2 * (wv >> 1) + (g >> 1)) * 64 + 16 * (2 * (wv & 1) + (g & 1)) + x) * 16));
                     } else {
 #pragma unroll

@@ -459,30 +459,33 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             else prep(yes_c, no_c, 0, -1);
         }
         __syncthreads();
-        for (int grp = ngrp - 1; grp >= 0; --grp) {
+        // steady state: stages ngrp-1 .. 2 (a full R + K preparation each); the last two stages are peeled so that the loop body
+        // is one straight preparation without the pipeline-tail cases
+        for (int grp = ngrp - 1; grp >= 2; --grp) {
             WKV6_T(ts0);
 #ifdef WKV6_STAMP
             asm volatile("" :: "v"(nr[0].x), "v"(nk[0].x), "v"(nr[1].x), "v"(nk[1].x));      // wait for the loads here
 #endif
             WKV6_T(ts1);
-            if (grp > 0) {
-                // the consuming roles are light enough that a stage waits for the producers: the next requests go out BEFORE the
-                // preparation and fly during all of it
-                take_r();                                          // r of stage s-1
-                if (grp > 1) {
-                    take_kw();                                     // k, w of stage s-2
-                    load_r(grp - 2);
-                    if (grp > 2) load_kw(grp - 3);
-                }
-                WKV6_T(ts2);
-                if (grp > 1) prep(yes_c, yes_c, grp - 1, grp - 2);
-                else prep(yes_c, no_c, 0, -1);
-            }
+            // the consuming roles are light enough that a stage waits for the producers: the next requests go out BEFORE the
+            // preparation and fly during all of it
+            take_r();                                              // r of stage s-1
+            take_kw();                                             // k, w of stage s-2
+            load_r(grp - 2);
+            if (grp > 2) load_kw(grp - 3);
+            WKV6_T(ts2);
+            prep(yes_c, yes_c, grp - 1, grp - 2);
             WKV6_T(ts3);
             __syncthreads();
             WKV6_T(ts4);
             WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3);
         }
+        if (ngrp >= 2) {                                           // stage 1 is consumed: only the R part of stage 0 is left to make
+            take_r();
+            prep(yes_c, no_c, 0, -1);
+            __syncthreads();
+        }
+        if (ngrp >= 1) __syncthreads();                            // stage 0 is consumed
     } else
     if (rowrole) {
         // =============== key rows [16wv, 16wv+16): gr, gk, gw, gu ==========================================
