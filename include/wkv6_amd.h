@@ -207,6 +207,14 @@ int wkv6_gn_gate_backward(long rows, int C, int H, const void* y, const void* g,
                           const float* stats, const void* dout, void* dy, void* dg, float* dgamma_part, float* dbeta_part,
                           int nparts, void* stream);
 
+/* Elementwise neighbours of the channel-mix FFN's GEMMs (src/model.py:636-644), bf16, n elements (a multiple of 8), one pass each:
+ * sqrelu: out = relu(x)^2, dx = 2 relu(x) dout;  sigmul: out = sigmoid(r) * kv, dr = dout kv s (1 - s), dkv = dout s.
+ * (The FFN's token shift and its two lerps are wkv6_ddlerp_* with NS = 2, m = NULL.) */
+int wkv6_sqrelu_forward(long n, const void* x, void* out, void* stream);
+int wkv6_sqrelu_backward(long n, const void* x, const void* dout, void* dx, void* stream);
+int wkv6_sigmul_forward(long n, const void* r, const void* kv, void* out, void* stream);
+int wkv6_sigmul_backward(long n, const void* r, const void* kv, const void* dout, void* dr, void* dkv, void* stream);
+
 /* Device self-test: the cross-lane primitives, then the chunked MFMA kernels against the exact scan kernels on a fixed
  * pseudo-random problem (forward and backward, all outputs within 2 bf16 ulps of the tensor scale, 4 for gw).
  * Returns 0 when it passes, WKV6_ESELFTEST (or the number of failed primitive checks) otherwise. */

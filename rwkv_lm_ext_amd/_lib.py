@@ -54,6 +54,10 @@ SIGNATURES = {
     "wkv6_ddlerp_rev_backward": (_I, [_I] * 4 + [_VP] * 9 + [_I, _VP]),
     "wkv6_gn_gate_forward": (_I, [_L, _I, _I] + [_VP] * 4 + [_F] + [_VP] * 3),
     "wkv6_gn_gate_backward": (_I, [_L, _I, _I] + [_VP] * 10 + [_I, _VP]),
+    "wkv6_sqrelu_forward": (_I, [_L] + [_VP] * 3),
+    "wkv6_sqrelu_backward": (_I, [_L] + [_VP] * 4),
+    "wkv6_sigmul_forward": (_I, [_L] + [_VP] * 4),
+    "wkv6_sigmul_backward": (_I, [_L] + [_VP] * 6),
     "wkv6_selftest": (_I, [_VP]),
     "wkv6_amd_version": (ctypes.c_char_p, []),
 }

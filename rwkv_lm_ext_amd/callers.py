@@ -210,17 +210,33 @@ class Tmix_x060(nn.Module):
 
 
 class CMix_x060(nn.Module):
-    """RWKV-6 channel-mix FFN (src/model.py:616-644): squared-ReLU key, sigmoid receptance gate."""
+    """RWKV-6 channel-mix FFN (src/model.py:616-644): squared-ReLU key, sigmoid receptance gate.  On bf16 GPU tensors the
+    elementwise glue between the three GEMMs runs as HIP kernels (mix_op: token shift + both lerps in one pass, relu^2, and
+    sigmoid * value in one pass each) instead of ten eager kernels; `fused` = None picks by tensor type, True / False force."""
 
-    def __init__(self, n_embd, dim_ffn):
+    def __init__(self, n_embd, dim_ffn, fused=None):
         super().__init__()
+        self.fused = fused
         self.time_maa_k = nn.Parameter(torch.zeros(1, 1, n_embd))
         self.time_maa_r = nn.Parameter(torch.zeros(1, 1, n_embd))
         self.key = nn.Linear(n_embd, dim_ffn, bias=False)
         self.receptance = nn.Linear(n_embd, n_embd, bias=False)
         self.value = nn.Linear(dim_ffn, n_embd, bias=False)
 
+    def _use_fused(self, x):
+        if self.fused is None:
+            from . import mix_op
+            C = x.shape[-1]
+            return (mix_op.fusable(x, self.time_maa_k, self.time_maa_r) and x.dim() == 3 and C % 64 == 0 and C <= 4096
+                    and self.key.weight.dtype == torch.bfloat16)
+        return self.fused
+
     def forward(self, x):
+        if self._use_fused(x):
+            from . import mix_op
+            xk, xr = mix_op.ddlerp(x, torch.cat([self.time_maa_k, self.time_maa_r], 0).view(2, -1))
+            k = mix_op.sqrelu(self.key(xk))
+            return mix_op.sigmoid_mul(self.receptance(xr), self.value(k))
         xx = F.pad(x, (0, 0, 1, -1)) - x
         k = torch.relu(self.key(x + xx * self.time_maa_k)) ** 2
         return torch.sigmoid(self.receptance(x + xx * self.time_maa_r)) * self.value(k)

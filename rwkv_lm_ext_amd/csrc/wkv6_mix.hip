@@ -4,6 +4,10 @@
 //   ddlerp  (src/model.py:435-448):  xx = shift(x) - x;   out_s = x + xx (.) (maa_s + m_s),  s = 0..NS-1
 //           NS = 1, m = null: the input of the first low-rank GEMM (x + xx (.) time_maa_x);
 //           NS = 5: xw, xk, xv, xr, xg from the five low-rank corrections m_s (the bmm output, [5,B,T,C] contiguous).
+//           NS = 2, m = null: the channel-mix FFN's two inputs x + xx (.) time_maa_k, x + xx (.) time_maa_r (src/model.py:636-638).
+//   sqrelu  (src/model.py:640-641):  out = relu(x)^2 on the FFN's key projection;   backward dx = 2 relu(x) dout.
+//   sigmul  (src/model.py:643-644):  out = sigmoid(r) (.) kv, the receptance gate on the FFN's value projection;
+//           backward dr = dout kv s (1 - s), dkv = dout s.
 //   gn_gate (src/model.py:462-468):  out = GroupNorm_H(y) (.) g  -- per-head normalisation of the WKV output over its 64
 //           channels (nn.GroupNorm(H, C, eps) on [B*T, C]) fused with the gate multiply that feeds the output GEMM.
 // Forward and backward of both; parameter gradients (time_maa_*, ln_x.weight/bias) leave as per-workgroup fp32 partial rows
@@ -251,6 +255,74 @@ __global__ void gn_gate_bwd_kernel(const GnArgs a)
     *reinterpret_cast<float4*>(a.dbeta_part + (long)blockIdx.x * a.C + c) = make_float4(accb[0], accb[1], accb[2], accb[3]);
 }
 
+// ---- flat elementwise kernels of the channel-mix FFN: 8 bf16 per lane (16-byte accesses), grid-stride over n / 8 units -----------
+struct FlatArgs {
+    long n8;                  // number of 8-element units (n / 8)
+    const bf16_t *a, *b, *dout;
+    bf16_t *out, *da, *db;
+};
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&o)[8])
+{
+    const uint4 raw = *reinterpret_cast<const uint4*>(p);
+    o[0] = bf_lo(raw.x); o[1] = bf_hi(raw.x); o[2] = bf_lo(raw.y); o[3] = bf_hi(raw.y);
+    o[4] = bf_lo(raw.z); o[5] = bf_hi(raw.z); o[6] = bf_lo(raw.w); o[7] = bf_hi(raw.w);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8])
+{
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+template <bool BWD> __global__ __launch_bounds__(256) void sqrelu_kernel(const FlatArgs a)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n8; i += (long)gridDim.x * blockDim.x) {
+        float x[8], o[8];
+        ld8(a.a + 8 * i, x);
+        if constexpr (BWD) {
+            float d[8];
+            ld8(a.dout + 8 * i, d);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = 2.f * fmaxf(x[q], 0.f) * d[q];
+            st8(a.da + 8 * i, o);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float r = fmaxf(x[q], 0.f); o[q] = r * r; }
+            st8(a.out + 8 * i, o);
+        }
+    }
+}
+template <bool BWD> __global__ __launch_bounds__(256) void sigmul_kernel(const FlatArgs a)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n8; i += (long)gridDim.x * blockDim.x) {
+        float r[8], kv[8], o[8];
+        ld8(a.a + 8 * i, r);
+        ld8(a.b + 8 * i, kv);
+        if constexpr (BWD) {
+            float d[8], o2[8];
+            ld8(a.dout + 8 * i, d);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float s = sigmoidf_(r[q]);
+                o[q] = d[q] * kv[q] * s * (1.f - s);
+                o2[q] = d[q] * s;
+            }
+            st8(a.da + 8 * i, o);
+            st8(a.db + 8 * i, o2);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = sigmoidf_(r[q]) * kv[q];
+            st8(a.out + 8 * i, o);
+        }
+    }
+}
+template <typename K> int launch_flat(K kernel, const FlatArgs& a, hipStream_t st)
+{
+    const long blocks = (a.n8 + 255) / 256;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? WKV6_OK : (int)e;
+}
+
 int check_rows(long rows, int C)
 {
     if (rows < 1 || C < 64 || C % 64 != 0 || C / 4 > 1024) return WKV6_EINVAL;
@@ -269,6 +341,7 @@ int dispatch_lerp(const LerpArgs& a, bool bwd, hipStream_t st)
     if (a.NS == 1 && !a.m) launch_lerp<1, false>(a, bwd, st);
     else if (a.NS == 5 && a.m) launch_lerp<5, true>(a, bwd, st);
     else if (a.NS == 1 && a.m) launch_lerp<1, true>(a, bwd, st);
+    else if (a.NS == 2 && !a.m) launch_lerp<2, false>(a, bwd, st);
     else return WKV6_EUNSUPPORTED;
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? WKV6_OK : (int)e;
@@ -317,6 +390,39 @@ int wkv6_ddlerp_rev_backward(int B, int T, int C, int NS, const void* x, const v
     a.rev_n = rev_n;
     a.dout = (const bf16_t*)dout; a.dx = (bf16_t*)dx; a.dm = (bf16_t*)dm; a.dmaa_part = dmaa_part; a.nparts = nparts;
     return dispatch_lerp(a, true, (hipStream_t)stream);
+}
+
+int wkv6_sqrelu_forward(long n, const void* x, void* out, void* stream)
+{
+    if (n < 8 || n % 8) return WKV6_EINVAL;
+    if (!x || !out) return WKV6_ENULL;
+    FlatArgs a = {};
+    a.n8 = n / 8; a.a = (const bf16_t*)x; a.out = (bf16_t*)out;
+    return launch_flat(sqrelu_kernel<false>, a, (hipStream_t)stream);
+}
+int wkv6_sqrelu_backward(long n, const void* x, const void* dout, void* dx, void* stream)
+{
+    if (n < 8 || n % 8) return WKV6_EINVAL;
+    if (!x || !dout || !dx) return WKV6_ENULL;
+    FlatArgs a = {};
+    a.n8 = n / 8; a.a = (const bf16_t*)x; a.dout = (const bf16_t*)dout; a.da = (bf16_t*)dx;
+    return launch_flat(sqrelu_kernel<true>, a, (hipStream_t)stream);
+}
+int wkv6_sigmul_forward(long n, const void* r, const void* kv, void* out, void* stream)
+{
+    if (n < 8 || n % 8) return WKV6_EINVAL;
+    if (!r || !kv || !out) return WKV6_ENULL;
+    FlatArgs a = {};
+    a.n8 = n / 8; a.a = (const bf16_t*)r; a.b = (const bf16_t*)kv; a.out = (bf16_t*)out;
+    return launch_flat(sigmul_kernel<false>, a, (hipStream_t)stream);
+}
+int wkv6_sigmul_backward(long n, const void* r, const void* kv, const void* dout, void* dr, void* dkv, void* stream)
+{
+    if (n < 8 || n % 8) return WKV6_EINVAL;
+    if (!r || !kv || !dout || !dr || !dkv) return WKV6_ENULL;
+    FlatArgs a = {};
+    a.n8 = n / 8; a.a = (const bf16_t*)r; a.b = (const bf16_t*)kv; a.dout = (const bf16_t*)dout; a.da = (bf16_t*)dr; a.db = (bf16_t*)dkv;
+    return launch_flat(sigmul_kernel<true>, a, (hipStream_t)stream);
 }
 
 int wkv6_gn_gate_forward(long rows, int C, int H, const void* y, const void* g, const void* gamma, const void* beta,

@@ -1,6 +1,7 @@
-"""Fused elementwise neighbours of the WKV6 operator in the RWKV-6 time-mix block, served by librwkv6_amd.so
-(csrc/wkv6_mix.hip): the token-shift / data-dependent-lerp chain in front of the projections (src/model.py:435-448,
-SURVEY.md row n4) and the per-head GroupNorm + gate behind the operator (src/model.py:462-468, row n1).
+"""Fused elementwise neighbours of the WKV6 operator in the RWKV-6 blocks, served by librwkv6_amd.so
+(csrc/wkv6_mix.hip): the token-shift / data-dependent-lerp chain in front of the time-mix projections (src/model.py:435-448,
+SURVEY.md row n4), the per-head GroupNorm + gate behind the operator (src/model.py:462-468, row n1), and the elementwise glue of
+the channel-mix FFN (token shift + two lerps, squared ReLU, sigmoid gate: src/model.py:636-644).
 
 bf16 GPU tensors only; like the operator itself there is no CPU path.  Each op is a torch.autograd.Function whose
 forward and backward are one HIP kernel each; parameter gradients come back as fp32 partial rows summed here."""
@@ -124,3 +125,67 @@ class _GroupNormGate(torch.autograd.Function):
 
 def group_norm_gate(y, g, gamma, beta, n_head, eps):
     return _GroupNormGate.apply(y, g, gamma, beta, n_head, eps)
+
+
+class _SqRelu(torch.autograd.Function):
+    """relu(x)^2 (src/model.py:640-641) in one pass; one rounding where the eager form rounds relu and the square separately (relu is
+    exact, so the results are identical)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _require(x, "x")
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().wkv6_sqrelu_forward(x.numel(), _ptr(x), _ptr(out), _stream_ptr())
+        _lib.check(rc, "sqrelu forward")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        dout = _require(dout, "dout")
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().wkv6_sqrelu_backward(x.numel(), _ptr(x), _ptr(dout), _ptr(dx), _stream_ptr())
+        _lib.check(rc, "sqrelu backward")
+        return dx
+
+
+class _SigMul(torch.autograd.Function):
+    """sigmoid(r) * kv (src/model.py:643-644) in one pass, rounded once."""
+
+    @staticmethod
+    def forward(ctx, r, kv):
+        r, kv = _require(r, "r"), _require(kv, "kv")
+        if r.shape != kv.shape:
+            raise RuntimeError("sigmoid_mul: r and kv must have the same shape")
+        out = torch.empty_like(r)
+        with torch.cuda.device(r.device):
+            rc = _lib.load().wkv6_sigmul_forward(r.numel(), _ptr(r), _ptr(kv), _ptr(out), _stream_ptr())
+        _lib.check(rc, "sigmul forward")
+        ctx.save_for_backward(r, kv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        r, kv = ctx.saved_tensors
+        dout = _require(dout, "dout")
+        dr, dkv = torch.empty_like(r), torch.empty_like(kv)
+        with torch.cuda.device(r.device):
+            rc = _lib.load().wkv6_sigmul_backward(r.numel(), _ptr(r), _ptr(kv), _ptr(dout), _ptr(dr), _ptr(dkv), _stream_ptr())
+        _lib.check(rc, "sigmul backward")
+        return dr, dkv
+
+
+def sqrelu(x):
+    return _SqRelu.apply(x)
+
+
+def sigmoid_mul(r, kv):
+    return _SigMul.apply(r, kv)
+
+
+def fusable(*tensors):
+    """The HIP elementwise path applies: bf16 GPU tensors whose element count is a multiple of 8."""
+    return all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.numel() % 8 == 0 for t in tensors)

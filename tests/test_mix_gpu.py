@@ -42,7 +42,7 @@ def ddlerp_ref(x, maa, m, first):
     return x + delta * (maa.view(-1, 1, 1, x.shape[-1]) + mm)
 
 
-@pytest.mark.parametrize("ns,has_m,carry", [(1, False, False), (5, True, False), (5, True, True), (1, True, True)])
+@pytest.mark.parametrize("ns,has_m,carry", [(1, False, False), (5, True, False), (5, True, True), (1, True, True), (2, False, False)])
 def test_ddlerp_forward_backward(mix, ns, has_m, carry):
     B, T, C = 3, 37, 256
     x = rnd(B, T, C, seed=1).requires_grad_(True)
@@ -245,3 +245,79 @@ def test_time_mix_module_with_the_fused_epilogue():
         tm.fuse_epilogue = False
     for n, a, b in zip(("out", "dx", "d ln_x.weight", "d time_faaaa"), res[True], res[False]):
         close(a, b.float(), "fused-epilogue module " + n, ulps=2.02, rms=3e-3)
+
+
+
+def test_channel_mix_glue_kernels(mix):
+    """sqrelu and sigmoid_mul (src/model.py:640-644) forward and backward against fp32 torch on the same bf16 inputs."""
+    x = rnd(5, 33, 512, scale=1.5, seed=21).requires_grad_(True)
+    xr = x.detach().float().cpu().requires_grad_(True)
+    out, ref = mix.sqrelu(x), torch.relu(xr) ** 2
+    close(out, ref, "sqrelu out")
+    d = rnd(5, 33, 512, seed=22)
+    out.backward(d)
+    ref.backward(d.float().cpu())
+    close(x.grad, xr.grad, "sqrelu dx")
+    r, kv = rnd(4, 50, 256, scale=2.0, seed=23).requires_grad_(True), rnd(4, 50, 256, seed=24).requires_grad_(True)
+    rr, kr = r.detach().float().cpu().requires_grad_(True), kv.detach().float().cpu().requires_grad_(True)
+    out, ref = mix.sigmoid_mul(r, kv), torch.sigmoid(rr) * kr
+    close(out, ref, "sigmul out")
+    d = rnd(4, 50, 256, seed=25)
+    out.backward(d)
+    ref.backward(d.float().cpu())
+    close(r.grad, rr.grad, "sigmul dr")
+    close(kv.grad, kr.grad, "sigmul dkv")
+
+
+def test_channel_mix_module_fused_equals_eager():
+    """CMix_x060 with the HIP glue kernels against its eager form (same bf16 parameters): the fused kernels round once where the
+    eager chain rounds after every op, so the comparison is at a few bf16 ulps; gradients likewise."""
+    from rwkv_lm_ext_amd import callers
+    torch.manual_seed(3)
+    C, F_ = 256, 896
+    cm = callers.CMix_x060(C, F_).cuda().to(bf)
+    with torch.no_grad():
+        cm.time_maa_k.uniform_(0.1, 0.9)
+        cm.time_maa_r.uniform_(0.1, 0.9)
+    x = rnd(3, 40, C, seed=31)
+    outs = []
+    for fused in (True, False):
+        cm.fused = fused
+        xi = x.clone().requires_grad_(True)
+        y = cm(xi)
+        y.backward(rnd(3, 40, C, seed=32))
+        outs.append((y.detach().float().cpu(), xi.grad.float().cpu(), cm.key.weight.grad.float().cpu().clone()))
+        cm.zero_grad()
+    for a_, b_, what in zip(outs[0], outs[1], ("y", "dx", "dW_key")):
+        assert float((a_ - b_).abs().max()) <= 3e-2 * float(b_.abs().max()), what
+    # against the fp32 module on the bf16-rounded parameters: the fused form (one rounding per kernel) is at least as close as the eager chain
+    ref = callers.CMix_x060(C, F_)
+    ref.load_state_dict({k: v.float().cpu() for k, v in cm.state_dict().items()})
+    want = ref(x.float().cpu())
+    e_fused = float((outs[0][0] - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+    e_eager = float((outs[1][0] - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+    assert e_fused <= 1.1 * e_eager + 1e-4 and e_fused <= 1e-2, (e_fused, e_eager)
+
+
+def test_lora_linear_epilogue_add_equals_eager():
+    """train_dp.LoraLinear on bf16 GPU tensors adds the low-rank term in the second GEMM's epilogue: same values as the eager
+    expression to bf16 rounding, same gradients for x, A and B; the frozen weight gets none."""
+    from rwkv_lm_ext_amd import train_dp
+    torch.manual_seed(5)
+    lin = train_dp.LoraLinear(256, 640, r=8, alpha=32.0).cuda().to(bf)
+    with torch.no_grad():
+        lin.lora_B.normal_(0.0, 0.05)
+    x = rnd(4, 30, 256, seed=41)
+    gy = rnd(4, 30, 640, seed=42)
+    xi = x.clone().requires_grad_(True)
+    y = lin(xi)                                        # fused path (bf16 GPU, no dropout)
+    y.backward(gy)
+    got = (y.detach().float(), xi.grad.float(), lin.lora_A.grad.float().clone(), lin.lora_B.grad.float().clone())
+    assert lin.weight.grad is None
+    lin.zero_grad()
+    xf = x.float().clone().requires_grad_(True)       # reference: the eager expression in fp32
+    W, A, Bm = lin.weight.float(), lin.lora_A.float().detach().requires_grad_(True), lin.lora_B.float().detach().requires_grad_(True)
+    yr = F.linear(xf, W) + lin.scaling * F.linear(F.linear(xf, A), Bm)
+    yr.backward(gy.float())
+    for a_, b_, what in zip(got, (yr.detach(), xf.grad, A.grad, Bm.grad), ("y", "dx", "dA", "dB")):
+        assert float((a_ - b_).abs().max()) <= 2e-2 * float(b_.abs().max()), what
