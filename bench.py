@@ -55,6 +55,15 @@ def add_counter_rows(rows, acc):
             per_dispatch[id_] = per_dispatch.get(id_, 0.0) + float(row["Counter_Value"])
     for (key, cname, _), val in per_dispatch.items():
         acc.setdefault(key, {}).setdefault(cname, []).append(val)
+    # whole passes (workloads of several launches per pass: wkv6_bi, infctx, two-level scans): every dispatch of this library's
+    # forward-side / backward-side kernels, summed
+    for row in rows:
+        kn = row["Kernel_Name"]
+        if "wkv6::" not in kn:
+            continue
+        side = "_pass_bwd" if ("bwd" in kn or "backward" in kn) else "_pass_fwd"
+        tot = acc.setdefault(side, {}).setdefault(row["Counter_Name"], [0.0])
+        tot[0] += float(row["Counter_Value"])
 
 
 def reduce_counters(acc):
@@ -62,13 +71,16 @@ def reduce_counters(acc):
     stream's bytes on gfx950 (MI355X_MICROARCH.md)."""
     out = {}
     for key, d in acc.items():
-        avg = {c: sum(v) / len(v) for c, v in d.items()}
+        if key.startswith("_pass_"):        # totals over the child's PMC_CHILD_STEPS passes -> per pass
+            avg = {c: v[0] / PMC_CHILD_STEPS for c, v in d.items()}
+        else:
+            avg = {c: sum(v) / len(v) for c, v in d.items()}
         if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
             out[key] = {"counters": avg, "hbm_bytes": int(2 * avg["FETCH_SIZE"] * 1024 + avg["WRITE_SIZE"] * 1024)}
     return out
 
 
-def pmc_live(timeout_s=75):
+def pmc_live(workload="wkv6", timeout_s=75):
     """HBM bytes and VALU utilisation of the two kernels, measured NOW: rank 0 at N = 1 runs this same script as a child under
     `rocprofv3 --kernel-trace --pmc <group>` (one run per counter group -- FETCH_SIZE and WRITE_SIZE cannot share a pass -- with a
     handful of fwd+bwd launches each) before it touches the GPU itself, and averages the counters per launch.  FETCH_SIZE is
@@ -89,7 +101,7 @@ def pmc_live(timeout_s=75):
         for i, grp in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])):
             out = os.path.join(tmp, f"g{i}")
             cmd = [prof, "--kernel-trace", "--pmc", *grp, "--output-format", "csv", "-d", out, "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child"]
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload]
             # own session: on a timeout the whole group goes (rocprofv3 AND the profiled python under it), so that no GPU holder
             # is left running beside the timed section
             child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -121,17 +133,15 @@ def under_profiler():
     return any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def pmc_child():
-    """The profiled child of pmc_live(): a few forward + backward launches of the headline workload, nothing else."""
-    from rwkv_lm_ext_amd import wkv6_op
-    dev = torch.device("cuda", 0)
-    B, T, H = 8, 4096, 32
-    r, k, v, w, u, gy = synth(B, T, H, dev)
-    y = torch.empty_like(r)
-    ckpt = wkv6_op.new_checkpoint(B, T, H * 64, H, dev)
-    for _ in range(6):
-        wkv6_op.forward_ex(r, k, v, w, u, H, y=y, ckpt=ckpt)
-        wkv6_op.backward_ex(r, k, v, w, u, gy, H, ckpt=ckpt)
+PMC_CHILD_STEPS = 6
+
+
+def pmc_child(workload):
+    """The profiled child of pmc_live(): PMC_CHILD_STEPS forward + backward passes of the workload, nothing else."""
+    fwd, bwd = build_workload(workload, torch.device("cuda", 0))[:2]
+    for _ in range(PMC_CHILD_STEPS):
+        fwd()
+        bwd()
     torch.cuda.synchronize()
 
 
@@ -242,75 +252,26 @@ def bench_dp_lora(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="wkv6", choices=["wkv6", "infctx", "bi", "dp_lora", "prefill"])
-    ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
-                    help="roofline.traffic of the headline workload: measured now under rocprofv3 (N = 1), from the committed PMC file, or omitted")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--layers", type=int, default=24, help="dp_lora: number of RWKV blocks (1B6: 24)")
-    ap.add_argument("--per-gpu-batch", type=int, default=32, help="dp_lora: triples per GPU and step")
-    args = ap.parse_args()
-    if args.pmc_child:
-        return pmc_child()
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # started as plain `python bench.py --gpus N`: spawn the ranks (nothing has touched the GPU yet) and relay
-        import socket
-        import subprocess
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    # the profiled child runs come first, before this process makes ANY torch.cuda call (no fork + exec from a process that holds a
-    # HIP context; the presence of a GPU is read from the device node, not from the runtime)
-    pmc, pmc_source = {}, None
-    if args.workload == "wkv6" and rank == 0 and args.traffic != "none" and os.path.exists("/dev/kfd"):
-        if args.traffic == "live" and world == 1:
-            pmc, pmc_source = pmc_live(), "rocprofv3 --pmc child runs of this invocation"
-        if not pmc:
-            pmc, pmc_source = pmc_from_file(), "profiles/" + os.path.basename(PMC_FILE)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the WKV6 operator has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-
+def build_workload(workload, dev, seed=0):
+    """(fwd, bwd, tokens, B, T, H, name) of one of the operator-level workloads: closures over synthetic inputs resident in HBM."""
     from rwkv_lm_ext_amd import wkv6_op
-
-    if args.workload == "dp_lora":
-        return bench_dp_lora(args, rank, world, dev, dist)
-    if args.workload == "wkv6":
+    if workload == "wkv6":
         B, T, H = 8, 4096, 32
         name = "wkv6_fwd_bwd B=8 T=4096 C=2048 H=32 (BASELINE configs[1])"
-    elif args.workload == "prefill":
+    elif workload == "prefill":
         B, T, H = 1, 16384, 32
         name = "WKV6 forward only (inference prefill) B=1 T=16384 C=2048, two-level scan over T; not a BASELINE config"
-    elif args.workload == "infctx":
+    elif workload == "infctx":
         B, T, H = 4, 16384, 32
         name = "wkv6infctx fwd+bwd B=4 T=16384 in 8 chunks of 2048, bf16 state carry (BASELINE configs[4])"
     else:
         B, T, H = 48, 512, 32
         name = "wkv6_bi fwd+bwd B=48 (16x3) T=512, mask lengths U[64,512] (BASELINE configs[2])"
     C = H * 64
-    r, k, v, w, u, gy = synth(B, T, H, dev, seed=rank)
+    r, k, v, w, u, gy = synth(B, T, H, dev, seed=seed)
     tokens = B * T
 
-    if args.workload == "wkv6":
+    if workload == "wkv6":
         y = torch.empty_like(r)
         ckpt = wkv6_op.new_checkpoint(B, T, C, H, dev)     # forward-state checkpoints, as WKV_6.apply keeps them
 
@@ -319,7 +280,7 @@ def main():
 
         def bwd():
             wkv6_op.backward_ex(r, k, v, w, u, gy, H, ckpt=ckpt)
-    elif args.workload == "prefill":
+    elif workload == "prefill":
         y = torch.empty_like(r)
 
         def fwd():
@@ -327,7 +288,7 @@ def main():
 
         def bwd():
             pass
-    elif args.workload == "infctx":
+    elif workload == "infctx":
         chunks = [slice(2048 * c, 2048 * (c + 1)) for c in range(8)]
         parts = [[x[:, sl].contiguous() for x in (r, k, v, w, gy)] for sl in chunks]
         states = [torch.zeros(B, H, 64, 64, device=dev, dtype=torch.bfloat16) for _ in range(9)]
@@ -353,6 +314,64 @@ def main():
 
         def bwd():
             wkv6_op.bi_backward_ex(mask, r, k, v, w, u, gy, H, ws=bi_ws)
+
+    return fwd, bwd, tokens, B, T, H, name
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="wkv6", choices=["wkv6", "infctx", "bi", "dp_lora", "prefill"])
+    ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
+                    help="roofline.traffic of the headline workload: measured now under rocprofv3 (N = 1), from the committed PMC file, or omitted")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--layers", type=int, default=24, help="dp_lora: number of RWKV blocks (1B6: 24)")
+    ap.add_argument("--per-gpu-batch", type=int, default=32, help="dp_lora: triples per GPU and step")
+    args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args.workload)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: spawn the ranks (nothing has touched the GPU yet) and relay
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    # the profiled child runs come first, before this process makes ANY torch.cuda call (no fork + exec from a process that holds a
+    # HIP context; the presence of a GPU is read from the device node, not from the runtime)
+    pmc, pmc_source = {}, None
+    if args.workload != "dp_lora" and rank == 0 and args.traffic != "none" and os.path.exists("/dev/kfd"):
+        if args.traffic == "live" and world == 1:
+            pmc, pmc_source = pmc_live(args.workload), "rocprofv3 --pmc child runs of this invocation"
+        if not pmc and args.workload == "wkv6":
+            pmc, pmc_source = pmc_from_file(), "profiles/" + os.path.basename(PMC_FILE)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the WKV6 operator has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rwkv_lm_ext_amd import wkv6_op
+
+    if args.workload == "dp_lora":
+        return bench_dp_lora(args, rank, world, dev, dist)
+    fwd, bwd, tokens, B, T, H, name = build_workload(args.workload, dev, seed=rank)
+    C = H * 64
 
     from rwkv_lm_ext_amd.dp import timed_steps
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
@@ -390,6 +409,13 @@ def main():
             {"64": "chunk_bwd64_kernel", "32": "chunk_bwd12_kernel", "12": "chunk_bwd12_kernel"}.get(os.environ.get("WKV6_BWD", ""),
                                                                                                   "chunk_bwd12k_kernel")
         ach = units * dom_b / (dom_ms * 1e-3) / 1e9
+
+        def traffic_of(kernel, side):
+            """HBM bytes of the dominant pass: one launch at the headline workload (per-launch average of its kernel), every
+            launch of the pass where a pass is several launches (wkv6_bi: two scans + helpers; infctx: eight chunks)."""
+            if args.workload == "wkv6" and pmc.get(kernel):
+                return pmc[kernel]["hbm_bytes"]
+            return pmc.get(side, {}).get("hbm_bytes")
         step_bytes = FWD_BYTES if args.workload == "prefill" else FWD_BYTES + BWD_BYTES
         step_ach = units * step_bytes / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
         out = {
@@ -409,13 +435,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4),
-                         "traffic": pmc.get(dom_kernel, {}).get("hbm_bytes"),
-                         "traffic_source": pmc_source if pmc.get(dom_kernel) else None,
+                         "traffic": traffic_of(dom_kernel, "_pass_bwd" if dom_name == "backward" else "_pass_fwd"),
+                         "traffic_source": pmc_source if (pmc.get(dom_kernel) or pmc.get("_pass_fwd")) else None,
                          "algorithmic_bytes_per_launch": units * dom_b, "avg_ms": round(dom_ms, 4),
                          "valu_busy": valu_busy_of(pmc.get(dom_kernel, {}).get("counters", {}))},
             "roofline_step": {"bound": "hbm", "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(step_ach / HBM_PEAK_GBPS, 4),
-                              "algorithmic_bytes": units * step_bytes},
+                              "algorithmic_bytes": units * step_bytes,
+                              "traffic": (pmc["_pass_fwd"]["hbm_bytes"] + pmc.get("_pass_bwd", {}).get("hbm_bytes", 0))
+                              if pmc.get("_pass_fwd") else None},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()

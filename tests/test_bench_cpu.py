@@ -52,7 +52,9 @@ def test_live_counter_rows_reduce_to_per_launch_hbm_bytes():
     acc = {}
     bench.add_counter_rows(rows, acc)
     out = bench.reduce_counters(acc)
-    assert list(out) == ["chunk_bwd12_kernel"]
+    assert sorted(out) == ["_pass_bwd", "chunk_bwd12_kernel"]
     assert out["chunk_bwd12_kernel"]["counters"] == {"FETCH_SIZE": 800.0, "WRITE_SIZE": 400.0}
     assert out["chunk_bwd12_kernel"]["hbm_bytes"] == (2 * 800 + 400) * 1024
+    # whole-pass totals (workloads of several launches per pass): every dispatch of the library's kernels, per child step
+    assert out["_pass_bwd"]["counters"] == {"FETCH_SIZE": 1600.0 / bench.PMC_CHILD_STEPS, "WRITE_SIZE": 800.0 / bench.PMC_CHILD_STEPS}
 

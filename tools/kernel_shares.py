@@ -7,6 +7,7 @@ import sys
 
 GROUPS = [("WKV6 forward", ("chunk_fwd_kernel",)), ("WKV6 backward", ("chunk_bwd", "scan_bwd")),
           ("token shift / ddlerp (HIP)", ("ddlerp",)), ("GroupNorm * gate (HIP)", ("gn_gate",)),
+          ("channel-mix glue (HIP)", ("sqrelu", "sigmul")),
           ("GEMM (rocBLAS / hipBLASLt)", ("Cijk", "gemm", "Gemm", "GEMM")), ("optimizer", ("adam", "Adam", "multi_tensor")),
           ("RCCL", ("nccl", "rccl")), ("layer norm", ("layer_norm", "LayerNorm", "layernorm")),
           ("softmax / loss", ("softmax", "log_softmax", "nll")), ("embedding / gather / scatter", ("embedding", "index", "gather", "scatter")),
