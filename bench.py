@@ -45,6 +45,7 @@ def pmc_from_file():
 def add_counter_rows(rows, acc):
     """Fold the rows of one rocprofv3 counter_collection.csv into acc[kernel][counter] = [value per dispatch]: a counter of one
     dispatch may come as several rows (one per dimension instance), which are summed."""
+    rows = list(rows)                   # (a csv.DictReader is consumed by the first pass)
     per_dispatch = {}
     for row in rows:
         kn = row["Kernel_Name"]

@@ -105,8 +105,8 @@ size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H);
 int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                     const void* w, const void* u, const void* s0, void* s_out, void* y,
                     unsigned flags, void* stream);
-/* Same as wkv6_forward_ex, and additionally stores the forward state at the entry of every 32-token stage
- * (fp32, wkv6_backward_workspace_bytes() bytes) into `ckpt` -- the activation checkpoint a following
+/* Same as wkv6_forward_ex, and additionally stores the forward state every 64 tokens (every 32 where two workgroups serve
+ * a (batch, head) pair; fp32, wkv6_backward_workspace_bytes() bytes in all) into `ckpt` -- the activation checkpoint a following
  * wkv6_backward_ex(..., workspace = ckpt, flags | WKV6_CKPT_VALID) consumes.  bf16 I/O, chunked kernels only;
  * returns WKV6_EUNSUPPORTED for WKV6_IO_F32 / WKV6_ALGO_SCAN. */
 int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,

@@ -35,7 +35,7 @@ def _assert_inputs(C, H, *tensors):
 
 
 def _keep_ckpt(ctx):
-    """Let the forward store its fp32 state checkpoints (8 B per token-channel, e.g. 537 MB per layer at B=8, T=4096, C=2048)
+    """Let the forward store its fp32 state checkpoints (4 B per token-channel, e.g. 268 MB per layer at B=8, T=4096, C=2048)
     for the backward?  Only when a backward will follow, and not with RWKV_AMD_NO_CKPT=1: then nothing is kept between the two
     calls and the backward rebuilds the checkpoints with a state pass (+≈0.23 ms at that shape) -- the choice when activation
     memory matters more than time."""
@@ -53,7 +53,7 @@ class WKV_6(torch.autograd.Function):
             _assert_inputs(C, H, r, k, v, w, u)
             ctx.B, ctx.T, ctx.C, ctx.H = B, T, C, H
             ctx.save_for_backward(r, k, v, w, u)
-            # when a backward will follow, let the forward store its per-32-token state checkpoints (fp32, 8 B per
+            # when a backward will follow, let the forward store its per-64-token state checkpoints (fp32, 4 B per
             # token-channel) so the backward does not have to recompute them with a state pass
             ctx.ckpt = wkv6_op.new_checkpoint(B, T, C, H, r.device) if _keep_ckpt(ctx) else None
             return wkv6_op.forward_ex(r, k, v, w, u, H, ckpt=ctx.ckpt)

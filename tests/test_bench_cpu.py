@@ -50,7 +50,7 @@ def test_live_counter_rows_reduce_to_per_launch_hbm_bytes():
             rows.append({"Kernel_Name": kn, "Counter_Name": "WRITE_SIZE", "Dispatch_Id": disp, "Counter_Value": "50.0"})
     rows.append({"Kernel_Name": "some_torch_kernel", "Counter_Name": "FETCH_SIZE", "Dispatch_Id": "3", "Counter_Value": "9e9"})
     acc = {}
-    bench.add_counter_rows(rows, acc)
+    bench.add_counter_rows(iter(rows), acc)          # a one-shot iterator, as csv.DictReader is
     out = bench.reduce_counters(acc)
     assert sorted(out) == ["_pass_bwd", "chunk_bwd12_kernel"]
     assert out["chunk_bwd12_kernel"]["counters"] == {"FETCH_SIZE": 800.0, "WRITE_SIZE": 400.0}
