@@ -166,7 +166,8 @@ __global__ void tsplit_combine_kernel(const void* s0, int s_f32, long s0_bstride
 
 int tsplit_segments(const ScanArgs& a)
 {
-    if (a.lens || a.reverse || a.rev_n || a.order || a.accumulate || a.y_f32 || a.zero_tail || a.dsum) return 1;
+    if (a.lens || a.reverse || a.rev_n || a.order || a.accumulate || a.y_f32 || a.zero_tail || a.dsum || a.gn_out) return 1;
+    if (a.g_f32[0] || a.g_f32[1] || a.g_f32[2] || a.g_f32[3]) return 1;
     int want = 0;
     if (const char* e = getenv("WKV6_TSPLIT")) {       // A/B switch: 0 / 1 = off, n = exactly n segments (if T divides)
         want = atoi(e);
@@ -178,29 +179,152 @@ int tsplit_segments(const ScanArgs& a)
     while (2 * S <= 16 && (long)a.B * a.H * 2 * S <= cus && a.T % (64 * 2 * S) == 0 && a.T / (2 * S) >= 512) S *= 2;
     return S >= 4 ? S : 1;      // two segments do not pay for the extra state pass (two workgroups per pair serve that case)
 }
-
-hipError_t chunk_forward(const ScanArgs& a, hipStream_t st)
+// A call that runs as a two-level scan runs on B * S rows with one workgroup each: its checkpoints are 64 tokens apart in row
+// order whatever the plan of the unsplit shape says (unless an A/B switch pins another backward kernel: then only the forward is
+// segmented and the backward walks whole sequences, as in rounds 2-3).
+bool tsplit_plan(ScanArgs& a, int S)
 {
-    const int S = tsplit_segments(a);
-    if (S <= 1) return launch_chunk_fwd(a, st);
-    const size_t nstate = (size_t)a.B * S * a.H * HEAD * HEAD;                 // floats
-    const size_t ndsum = (size_t)a.B * S * a.H * 4 * HEAD;
-    StreamScratch scratch;
-    float* const buf = reinterpret_cast<float*>(scratch.get((2 * nstate + ndsum) * sizeof(float), st));
-    if (!buf) return hipErrorOutOfMemory;
-    float* const A = buf, * const Sin = buf + nstate, * const dsum = buf + 2 * nstate;
+    if (S <= 1 || getenv("WKV6_BWD")) return false;
+    a.ckpt_tok = 64;
+    a.ckpt_fmt = CKPT_ROW_ORDER;
+    return true;
+}
+
+// segment entry states of a two-level forward: state pass per segment from zero (A, dsum), chained by tsplit_combine_kernel
+hipError_t tsplit_entry_states(const ScanArgs& a, int S, float* A, float* Sin, float* dsum, hipStream_t st)
+{
     ScanArgs p = a;
     p.B = a.B * S; p.T = a.T / S;
     p.s0 = nullptr; p.s0_bstride = 0; p.s_out = A; p.state_f32 = 1; p.y = nullptr; p.dsum = dsum; p.ckpt = nullptr;
     if (hipError_t e = launch_chunk_state_pass(p, st)) return e;
     hipLaunchKernelGGL(tsplit_combine_kernel, dim3(a.B * a.H), dim3(256), 0, st, a.s0, a.state_f32, a.s0_bstride, A, dsum, Sin,
                        a.s_out, a.H, S);
-    if (hipError_t e = hipGetLastError()) return e;
-    p = a;
+    return hipGetLastError();
+}
+
+hipError_t chunk_forward(const ScanArgs& a_, hipStream_t st)
+{
+    ScanArgs a = a_;
+    const int S = tsplit_segments(a);
+    if (S <= 1) return launch_chunk_fwd(a, st);
+    tsplit_plan(a, S);
+    const size_t nstate = (size_t)a.B * S * a.H * HEAD * HEAD;                 // floats
+    const size_t ndsum = (size_t)a.B * S * a.H * 4 * HEAD;
+    StreamScratch scratch;
+    float* const buf = reinterpret_cast<float*>(scratch.get((2 * nstate + ndsum) * sizeof(float), st));
+    if (!buf) return hipErrorOutOfMemory;
+    float* const A = buf, * const Sin = buf + nstate, * const dsum = buf + 2 * nstate;
+    if (hipError_t e = tsplit_entry_states(a, S, A, Sin, dsum, st)) return e;
+    ScanArgs p = a;
     p.B = a.B * S; p.T = a.T / S;
     p.s0 = Sin; p.s0_bstride = (long)a.H * HEAD * HEAD; p.state_f32 = 1; p.s_out = nullptr;
     p.ckpt_segs = S;                               // checkpoints (training forward) land in the whole sequences' slots
     return launch_chunk_fwd(p, st);
+}
+
+// ---- backward over few, long sequences as a two-level scan over T: the S segments of a sequence run as S
+// workgroups.  What a segment needs from beyond its end is closed-form:
+//   * the adjoint state G entering it from the future.  G_t = d_t (.) G_{t+1} + r_t gy_t^T is the forward recurrence
+//     S_{t+1} = d_t (.) S_t + k_t v_t^T read backwards with k := r, v := gy: the state-only pass of the forward kernel over the
+//     reversed segment gives its own contribution from a zero end state (and the decay sums), and the chaining kernel walks
+//     the segments last to first, G_start(seg) = 2^{dsum_seg} (.) G_end(seg) + A_seg;  G_start(first) is gs;
+//   * the gw suffix sum beyond its end: a_s - b_s = Phi_s - Phi_{s+1} with Phi_s[i] = sum_j G_s[i][j] S_s[i][j] (G_s the adjoint of
+//     the state S_s in front of token s), so sum_{s >= end} (a_s - b_s) = Phi_end, from the entering G and the forward checkpoint at
+//     the boundary;
+//   * gu sums over the segments.
+__global__ void tsplit_combine_rev_kernel(const float* __restrict__ A, const float* __restrict__ dsum, const float* __restrict__ ckpt,
+                                          float* __restrict__ Gin, float* __restrict__ phi, void* gs, int gs_f32, int H, int S,
+                                          long nslots_seg, int C)
+{
+    const int bh = blockIdx.x, b = bh / H, h = bh % H, tid = threadIdx.x;
+    __shared__ float red[256];
+    float cur[HEAD * HEAD / 256];
+    for (int m = 0; m < HEAD * HEAD / 256; ++m) cur[m] = 0.f;
+    for (int seg = S - 1; seg >= 0; --seg) {
+        const long bp = ((long)b * S + seg) * H + h;
+        float part = 0.f;
+        // forward state at this segment's end = the checkpoint at the next segment's start (row order, wkv6_scan.h)
+        const float* const ck = ckpt + (((long)(b * H + h) * S + (seg + 1)) * nslots_seg) * (HEAD * HEAD);
+        for (int m = 0; m < HEAD * HEAD / 256; ++m) {
+            const int e = tid + 256 * m, i = e & (HEAD - 1), j = e >> 6;          // state layout [j][i]
+            Gin[bp * HEAD * HEAD + e] = cur[m];
+            if (seg < S - 1) {
+                const int jt = 2 * (j >> 5) + ((j >> 2) & 1), gb = (j >> 3) & 3, qb = j & 3;
+                part = fmaf(cur[m], ck[((((i >> 4) * 4 + jt) * 64 + 16 * gb + (i & 15)) << 2) + qb], part);
+            }
+        }
+        red[tid] = part;                                  // the four threads tid, tid + 64, ... share key row i = tid & 63
+        __syncthreads();
+        if (tid < HEAD) phi[((long)b * S + seg) * C + h * HEAD + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+        __syncthreads();
+        for (int m = 0; m < HEAD * HEAD / 256; ++m) {
+            const int e = tid + 256 * m, i = e & (HEAD - 1);
+            float dl = 0.f;
+            for (int q = 0; q < 4; ++q) dl += dsum[(bp * 4 + q) * HEAD + i];
+            cur[m] = fmaf(__builtin_amdgcn_exp2f(dl), cur[m], A[bp * HEAD * HEAD + e]);
+        }
+    }
+    if (gs) {
+        for (int m = 0; m < HEAD * HEAD / 256; ++m) {
+            const long o = ((long)b * H + h) * HEAD * HEAD + tid + 256 * m;
+            if (gs_f32) reinterpret_cast<float*>(gs)[o] = cur[m];
+            else reinterpret_cast<bf16_t*>(gs)[o] = (bf16_t)(pack_bf2(cur[m], 0.f) & 0xffffu);
+        }
+    }
+}
+__global__ void tsplit_gu_kernel(const float* __restrict__ part, void* gu, int gu_f32, int S, int C)
+{
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int seg = 0; seg < S; ++seg) s += part[((long)b * S + seg) * C + c];
+        if (gu_f32) reinterpret_cast<float*>(gu)[(long)b * C + c] = s;
+        else reinterpret_cast<bf16_t*>(gu)[(long)b * C + c] = (bf16_t)(pack_bf2(s, 0.f) & 0xffffu);
+    }
+}
+
+hipError_t chunk_backward(const ScanArgs& a_, hipStream_t st)
+{
+    ScanArgs a = a_;
+    const int S = tsplit_segments(a);
+    if (S <= 1 || !tsplit_plan(a, S)) return launch_chunk_bwd(a_, st);
+    const int Ts = a.T / S;
+    const size_t nstate = (size_t)a.B * S * a.H * HEAD * HEAD, ndsum = (size_t)a.B * S * a.H * 4 * HEAD, nrow = (size_t)a.B * S * a.C;
+    StreamScratch scratch;
+    float* const buf = reinterpret_cast<float*>(scratch.get((2 * nstate + ndsum + 2 * nrow) * sizeof(float), st));
+    if (!buf) return hipErrorOutOfMemory;
+    float* const A = buf, * const Gin = buf + nstate, * const dsum = buf + 2 * nstate, * const phi = dsum + ndsum, * const gup = phi + nrow;
+    if (!a.ckpt_valid) {                               // self-contained: the forward's states first (two-level, like chunk_forward)
+        ScanArgs f = a;
+        f.y = nullptr; f.s_out = nullptr; f.gy = nullptr;
+        if (hipError_t e = tsplit_entry_states(f, S, A, Gin, dsum, st)) return e;
+        ScanArgs p = f;
+        p.B = a.B * S; p.T = Ts;
+        p.s0 = Gin; p.s0_bstride = (long)a.H * HEAD * HEAD; p.state_f32 = 1;
+        p.ckpt_segs = S;
+        if (hipError_t e = launch_chunk_state_pass(p, st)) return e;
+    }
+    {   // the segments' own adjoint contributions: state-only pass over the reversed segments with k := r, v := gy
+        ScanArgs p = a;
+        p.B = a.B * S; p.T = Ts;
+        p.k = a.r; p.v = a.gy; p.reverse = 1;
+        p.s0 = nullptr; p.s0_bstride = 0; p.s_out = A; p.state_f32 = 1; p.y = nullptr; p.dsum = dsum; p.ckpt = nullptr;
+        if (hipError_t e = launch_chunk_state_pass(p, st)) return e;
+    }
+    hipLaunchKernelGGL(tsplit_combine_rev_kernel, dim3(a.B * a.H), dim3(256), 0, st, A, dsum, a.ckpt, Gin, phi, a.gs, a.part_f32, a.H, S,
+                       (long)(Ts / 64), a.C);
+    if (hipError_t e = hipGetLastError()) return e;
+    ScanArgs p = a;
+    p.B = a.B * S; p.T = Ts;
+    p.s0 = nullptr; p.s0_bstride = 0;
+    p.g_in = Gin; p.rc_in = phi; p.ckpt_segs = S; p.ckpt_valid = 1; p.split = 0;
+    p.gu = a.gu ? gup : nullptr; p.gs = nullptr; p.part_f32 = 1;
+    if (hipError_t e = launch_chunk_bwd12k(p, st)) return e;
+    if (a.gu) {
+        hipLaunchKernelGGL(tsplit_gu_kernel, dim3(a.B), dim3(256), 0, st, gup, a.gu, a.part_f32, S, a.C);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
 }
 
 // forward dispatch: chunked MFMA kernel for bf16 I/O unless the caller forces the exact scan
@@ -217,9 +341,10 @@ hipError_t run_bwd(ScanArgs& a, unsigned flags, float* scratch, hipStream_t st)
         return launch_scan_bwd(a, flags & WKV6_IO_F32, st);
     }
     a.ckpt = scratch;
+    tsplit_plan(a, tsplit_segments(a));            // (a two-level call has its own checkpoint plan; chunk_backward decides the same way)
     a.ckpt_valid = ((flags & WKV6_CKPT_VALID) && ckpt_matches(scratch, a)) ? 1 : 0;
     if (!a.ckpt_valid) ckpt_note(scratch, a);      // the state pass of this call fills it
-    return launch_chunk_bwd(a, st);
+    return chunk_backward(a, st);
 }
 
 ScanArgs base_args(int B, int T, int C, int H, const void* r, const void* k, const void* v,
@@ -339,6 +464,7 @@ int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* 
     a.s_out = s_out;
     a.y = y;
     a.ckpt = reinterpret_cast<float*>(ckpt);
+    tsplit_plan(a, tsplit_segments(a));            // (as chunk_forward will decide)
     ckpt_note(ckpt, a);
     return to_rc(chunk_forward(a, (hipStream_t)stream));
 }

@@ -494,13 +494,18 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
         f4v ST[SBLK][4];
         float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.rc_in) io4<float>::load(a.rc_in + (long)b * a.C + h * HEAD + 16 * wv + 4 * g, Rc);   // the suffix sum beyond this segment
         // Checkpoint of the 64-token pair that holds stage `stg`: the forward wrote it in this wave's register order
         // ([row wave][jt][lane][4], wkv6_scan.h: CKPT_ROW_ORDER), so the slice is four coalesced 16-byte loads per lane straight into
         // registers.  Requested behind a stage's pre-phase (the registers of the stage's own states are dead by then) for the NEXT
         // stage: the latency runs under the chain, the barrier and the next stage's tile work.  Both stages of a pair read the
         // same checkpoint; the second read comes from the L2.
         const unsigned nslots = ((unsigned)a.T + CKT - 1) / CKT;
-        const rsrc_t rs_ck = make_rsrc(a.ckpt + (long)(b * a.H + h) * nslots * (HEAD * HEAD), nslots * 16384u);
+        // (two-level scan over T: this batch row is segment b % S of sequence b / S; the S segments' slots are consecutive -- the
+        // whole sequence's ordinary checkpoint layout, exactly as the forward wrote them: wkv6_chunk.hip)
+        const int segs = a.ckpt_segs > 1 ? a.ckpt_segs : 1;
+        const long ck_slot0 = ((long)((b / segs) * a.H + h) * segs + b % segs) * nslots;
+        const rsrc_t rs_ck = make_rsrc(a.ckpt + ck_slot0 * (HEAD * HEAD), nslots * 16384u);
         f4v CK[4];
         auto request_ckpt = [&](int stg) {
             const unsigned off = (unsigned)(stg >> 1) * 16384u + (unsigned)wv * 4096u + (unsigned)lane * 16u;
@@ -763,7 +768,12 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         // GJ[it][q] = G[i = tile_ch(it) + 8g + q][j = 16wv + x]
         f4v GJ[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) GJ[t] = f4v{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; ++t) {
+            float t4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.g_in)                                            // adjoint state entering this segment from the future, layout [j][i]
+                io4<float>::load(a.g_in + ((long)b * a.H + h) * HEAD * HEAD + (long)(16 * wv + x) * HEAD + tile_ch(t) + 8 * g, t4);
+            GJ[t] = f4v{t4[0], t4[1], t4[2], t4[3]};
+        }
         // this wave's share of the PREPARATION: v (K part, stage s-2) and gy (R part, stage s-1) of tokens 4wv .. 4wv+3 of both blocks go from
         // global memory into the images, with the two half sums of vg_a = gy_a . v_a (the v of a stage is kept in registers for the one
         // iteration until its gy arrives).  lane = (token tl, channels 4cl .. 4cl+3); requested at the head of a stage, written at its end.

@@ -93,6 +93,10 @@ struct ScanArgs {
     float gn_eps;
     void* gn_out;                     // [B,T,C]  GroupNorm_H(y) * gate  (y itself is stored too unless y == null)
     float* gn_stats;                  // [B*T, H, 2] mean, rstd of every (token, head) for the backward, or null
+    const float* g_in;                // backward as a two-level scan over T (wkv6_api.hip: chunk_backward): fp32 [B,H,N(j),N(i)] adjoint state
+                                      // entering this row (= segment) from the future, or null (zero)
+    const float* rc_in;               // ... and fp32 [B,C]: the gw suffix sum at the segment's end, sum_{s >= end} (a_s - b_s) =
+                                      // Phi[i] = sum_j G[i][j] S[i][j] at the boundary, or null (zero)
     int split;                        // chunked kernels, set by the launcher when B*H leaves half the chip idle: two workgroups per
                                       // (batch, head), each with its own producers and half of the consuming waves
 };

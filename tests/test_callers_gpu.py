@@ -187,7 +187,7 @@ def test_bi_encoder_training_step_gradients():
     loss_sw.backward()
     assert abs(float(loss) - float(loss_ref)) <= 2e-2, (float(loss), float(loss_ref))     # [1.4e-3 with the eager FFN, 1.2e-2 with the fused one] a bf16 model against its fp32 self
     assert abs(float(loss) - float(loss_twin)) <= 3e-2, (float(loss), float(loss_twin))   # [9e-3 eager FFN; 2.2e-2 fused: the two bf16 pipelines sit 1.2e-2 above / 1.1e-2 below the fp32 loss]
-    assert abs(float(loss) - float(loss_sw)) <= 5e-3, (float(loss), float(loss_sw))
+    assert abs(float(loss) - float(loss_sw)) <= 1e-2, (float(loss), float(loss_sw))       # [6.5e-3 with the fused FFN in both copies; the InfoNCE logits are 20 x cosines]
     checked, worst, worst_ref, worst_sw = 0, 0.0, 0.0, 0.0
     for (n, p), (_, pr), (_, pt), (_, ps) in zip(enc.named_parameters(), ref.named_parameters(), twin.named_parameters(),
                                                  swapped.named_parameters()):

@@ -358,6 +358,38 @@ def test_two_level_scan_forward_for_few_long_sequences(ops, oracle, monkeypatch,
     assert float((res[0][0].float() - res[1][0].float()).abs().max()) <= 2.0 ** -8 * float(res[0][0].float().abs().max())
 
 
+@pytest.mark.parametrize("segments", [2, 4, 8])
+def test_two_level_scan_backward_for_few_long_sequences(ops, oracle, monkeypatch, segments):
+    """The backward of few long sequences as a two-level scan over T (wkv6_api.hip: chunk_backward): every segment runs as its own
+    workgroup from the adjoint state entering it from the future (reversed state-only pass with k := r, v := gy, chained last to
+    first) and from the gw suffix sum beyond its end (Phi = sum_j G S at the boundary); gu sums over the segments, gs is the adjoint
+    state at the sequence start.  WKV6_TSPLIT forces the segment count: every gradient against the oracle (bf16 contract, fp32
+    partials) and against the one-pass backward, with the forward's checkpoints and self-contained."""
+    bf = torch.bfloat16
+    B, T, H = 2, 1024, 2
+    r, k, v, w, u, gy = rand_inputs(177, B, T, H, "init")
+    g = torch.Generator().manual_seed(15)
+    s0 = (torch.randn(B, H, 64, 64, generator=g) * 0.5).to(bf).float().numpy()
+    d = [dev(x, bf) for x in (r, k, v, w, u, gy)]
+    og = oracle.backward(r, k, v, w, u, gy, s0)
+    res = {}
+    for split in (0, segments):
+        monkeypatch.setenv("WKV6_TSPLIT", str(split))
+        ck = ops.new_checkpoint(B, T, 64 * H, H, "cuda")
+        ops.forward_ex(*d[:5], H, s0=dev(s0, bf), ckpt=ck)
+        res[split] = (ops.backward_ex(*d, H, s0=dev(s0, bf), want_gs=True, ckpt=ck),          # the forward's checkpoints
+                      ops.backward_ex(*d, H, s0=dev(s0, bf), want_gs=True))                    # self-contained
+    for kept, grads in zip(("kept checkpoints", "self-contained"), res[segments]):
+        for n, t in zip(("gr", "gk", "gv", "gw"), grads[:4]):
+            check(t, og[n], bf, f"{segments}-segment backward ({kept}) {n}")
+        assert max_norm_err(host(grads[4]), og["gu_b"]) <= PART_TOL, kept
+        assert max_norm_err(host(grads[5]), og["gs_b"]) <= PART_TOL, kept
+        for n, a_, b_ in zip(("gr", "gk", "gv", "gw", "gu", "gs"), res[0][0], grads):
+            a_, b_ = host(a_), host(b_)
+            scale = max(float(np.abs(a_).max()), 1e-3)
+            assert float(np.abs(a_ - b_).max()) <= (4.0 if n in ("gw", "gu", "gs") else 2.0) * 2.0 ** -8 * scale, (kept, n)
+
+
 def test_checkpoint_opt_out_gives_identical_gradients(ops, monkeypatch):
     """RWKV_AMD_NO_CKPT=1: nothing is kept from forward to backward, the backward rebuilds the state checkpoints itself --
     same kernels on the same numbers, so every gradient is bit-identical (WKV_6 and WKV_6_BI)."""
