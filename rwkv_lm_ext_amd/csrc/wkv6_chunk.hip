@@ -285,12 +285,20 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         const rsrc_t rs_ck = make_rsrc(a.ckpt ? a.ckpt + ck_slot0 * (HEAD * HEAD) : nullptr, a.ckpt ? nst * 16384u : 0u);
         // ACC (second half of wkv6_bi): the addend of a block is requested one block ahead, so that its HBM latency runs under
         // the previous block's MFMAs instead of in front of the store
+        // (wkv6_bi's halves go through buffer resources over the row's first ntok tokens like the plain path: tokens past the end
+        // read zero / are dropped by the hardware -- no per-lane predicates, no 64-bit address arithmetic)
         float acc_old[4] = {0.f, 0.f, 0.f, 0.f};
+        const unsigned nb_y = (!STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * a.C : 0u;
+        const rsrc_t rs_yf = make_rsrc(a.y_f32 ? a.y_f32 + base : nullptr, (a.y_f32 && !STATE_ONLY && ntok > 0) ? nb_y * 4u + 256u : 0u);
         auto acc_fetch = [&](int p) {
-            const int pc = p < ntok ? p : 0;
-            const unsigned idx = (unsigned)(tokmap(pc, REV_Y) * a.C + 16 * wv + 4 * g);
-            if (a.y_f32) io4<float>::load(a.y_f32 + base + idx, acc_old);
-            else io4<bf16_t>::load(gy_ + idx, acc_old);
+            const unsigned idx = (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g);
+            if (a.y_f32) {
+                const float4 t = buf_load16f(rs_yf, idx * 4u);
+                acc_old[0] = t.x; acc_old[1] = t.y; acc_old[2] = t.z; acc_old[3] = t.w;
+            } else {
+                const uint2 t = buf_load8(rs_y, idx * 2u);
+                acc_old[0] = bf_lo(t.x); acc_old[1] = bf_hi(t.x); acc_old[2] = bf_lo(t.y); acc_old[3] = bf_hi(t.y);
+            }
         };
         if constexpr (ACC) acc_fetch(x);
         // GN epilogue state: this group's y (bf16-rounded) and gate per block, the channel's affine parameters
@@ -440,18 +448,14 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                                     *reinterpret_cast<float*>(gn_stat + (grp & 1) * 2048 + ((wv * NBLK + blk) * 16 + x) * 8 + (g >> 1) * 4) = red;
                             }
                         } else {
-                            const bool valid = p < ntok;
-                            const int pc = valid ? p : 0;                // padding lanes still form a legal address
-                            const unsigned idx = (unsigned)(tokmap(pc, REV_Y) * a.C + 16 * wv + 4 * g);
+                            const unsigned idx = (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g);
                             if constexpr (ACC) {
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) o[q] += acc_old[q];      // fetched a block ago
                                 acc_fetch(p + BLK);                                   // the next block's addend: a block's work to arrive
                             }
-                            if (valid) {
-                                if (!ACC && a.y_f32) io4<float>::store(a.y_f32 + base + idx, o);
-                                else io4<bf16_t>::store(gy_ + idx, o);
-                            }
+                            if (!ACC && a.y_f32) buf_store16f(rs_yf, idx * 4u, o);
+                            else buf_store8(rs_y, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
                         }
                     }
                 }

@@ -139,33 +139,37 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // buffer resources over this row's first ntok tokens (wkv6_common.h): loads past the end return 0, stores are dropped
     const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
     const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);
-    // addend of a second-half store (GEN == 2), to be requested ahead of time: the first half's fp32 side buffer (or the output)
-    auto fetch_old = [&](int which, bf16_t* out, int p, unsigned bit, int ch, float (&old)[4]) {
+    // wkv6_bi's halves: the first (GEN == 1) writes its four gradients into fp32 side buffers (or, without them, the outputs), the
+    // second (GEN == 2) requests them ahead of the work whose result they meet, adds and rounds once.  Side buffers and outputs alike
+    // go through buffer resources over the row's first ntok tokens: tokens past the end read zero / are dropped by the hardware.
+    const unsigned nbytes4 = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 4u + 256u : 0u;
+    const rsrc_t rs_side[4] = {make_rsrc(GEN && a.g_f32[0] ? a.g_f32[0] + base : nullptr, GEN && a.g_f32[0] ? nbytes4 : 0u),
+                               make_rsrc(GEN && a.g_f32[1] ? a.g_f32[1] + base : nullptr, GEN && a.g_f32[1] ? nbytes4 : 0u),
+                               make_rsrc(GEN && a.g_f32[2] ? a.g_f32[2] + base : nullptr, GEN && a.g_f32[2] ? nbytes4 : 0u),
+                               make_rsrc(GEN && a.g_f32[3] ? a.g_f32[3] + base : nullptr, GEN && a.g_f32[3] ? nbytes4 : 0u)};
+    auto fetch_old = [&](int which, const rsrc_t& rs, int p, unsigned bit, int ch, float (&old)[4]) {
         if constexpr (GEN == 2) {
-            const int pc = p < ntok ? p : 0;                         // padding lanes still form a legal address
-            const unsigned idx = (unsigned)(tokmap(pc, bit) * a.C + ch);
-            float* const side = a.g_f32[which];
-            if (side) io4<float>::load(side + base + idx, old);
-            else io4<bf16_t>::load(out + idx, old);
+            const unsigned idx = (unsigned)(tokmap(p, bit) * a.C + ch);
+            if (a.g_f32[which]) {
+                const float4 t = buf_load16f(rs_side[which], idx * 4u);
+                old[0] = t.x; old[1] = t.y; old[2] = t.z; old[3] = t.w;
+            } else {
+                const uint2 t = buf_load8(rs, idx * 2u);
+                old[0] = bf_lo(t.x); old[1] = bf_hi(t.x); old[2] = bf_lo(t.y); old[3] = bf_hi(t.y);
+            }
         }
     };
-    // gradient store of scan position p, channels ch..ch+3: plain; or (wkv6_bi) first half into the fp32 side buffer, second half
-    // adds it and rounds once
-    auto emit = [&](int which, const rsrc_t& rs, bf16_t* out, int p, unsigned bit, int ch, float (&o)[4], const float (&old)[4]) {
+    // gradient store of scan position p, channels ch..ch+3
+    auto emit = [&](int which, const rsrc_t& rs, int p, unsigned bit, int ch, float (&o)[4], const float (&old)[4]) {
         const unsigned idx = (unsigned)(tokmap(p, bit) * a.C + ch);
-        if constexpr (GEN == 0) {
-            buf_store8(rs, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
-        } else if constexpr (GEN == 1) {
-            if (p >= ntok) return;
-            float* const side = a.g_f32[which];
-            if (side) io4<float>::store(side + base + idx, o);
-            else io4<bf16_t>::store(out + idx, o);
-        } else {
-            if (p >= ntok) return;
+        if constexpr (GEN == 1) {
+            if (a.g_f32[which]) { buf_store16f(rs_side[which], idx * 4u, o); return; }
+        }
+        if constexpr (GEN == 2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] += old[q];
-            io4<bf16_t>::store(out + idx, o);
         }
+        buf_store8(rs, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
     };
 
 #ifdef WKV6_STAMP
@@ -637,7 +641,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 const char* const rb = rpart(grp, blk);
                 const char* const kb = kpart(grp, blk);
                 float old_gr[4] = {0.f, 0.f, 0.f, 0.f};
-                fetch_old(0, ogr, grp * STG + blk * BLK + x, REV_R, 16 * wv + 4 * g, old_gr);
+                fetch_old(0, rs_gr, grp * STG + blk * BLK + x, REV_R, 16 * wv + 4 * g, old_gr);
                 b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: the B operand of accs
 #pragma unroll
                 for (int s = 0; s < 2; ++s) gyr[s] = ld_b8(rb + R_GY * ARR + x * RSB + (32 * s + 8 * g) * 2);
@@ -694,7 +698,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         at[blk][q] = rv[q] * dq;
                     }
                     const int p = grp * STG + blk * BLK + x;
-                    emit(0, rs_gr, ogr, p, REV_R, ch, o_gr, old_gr);
+                    emit(0, rs_gr, p, REV_R, ch, o_gr, old_gr);
                 }
             }
             WKV6_T(ts3);
@@ -708,8 +712,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 const char* const rb = rpart(grp, blk);
                 const char* const kb = kpart(grp, blk);
                 float old_gk[4] = {0.f, 0.f, 0.f, 0.f}, old_gw[4] = {0.f, 0.f, 0.f, 0.f};
-                fetch_old(1, ogk, grp * STG + blk * BLK + x, REV_K, 16 * wv + 4 * g, old_gk);
-                fetch_old(3, ogw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw);
+                fetch_old(1, rs_gk, grp * STG + blk * BLK + x, REV_K, 16 * wv + 4 * g, old_gk);
+                fetch_old(3, rs_gw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw);
                 f4v acck = gvb[blk];
                 acck += ackp[blk];
                 {
@@ -744,8 +748,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         Rc[q] += total;
                     }
                     const int p = grp * STG + blk * BLK + x;
-                    emit(1, rs_gk, ogk, p, REV_K, ch, o_gk, old_gk);
-                    emit(3, rs_gw, ogw, p, REV_W, ch, o_gw, old_gw);
+                    emit(1, rs_gk, p, REV_K, ch, o_gk, old_gk);
+                    emit(3, rs_gw, p, REV_W, ch, o_gw, old_gw);
                 }
             }
             WKV6_T(ts4);
@@ -899,7 +903,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const kb = kpart(grp, blk);
                 float old_gv[4] = {0.f, 0.f, 0.f, 0.f};
-                fetch_old(2, ogv, grp * STG + blk * BLK + x, REV_V, 16 * wv + 4 * g, old_gv);
+                fetch_old(2, rs_gv, grp * STG + blk * BLK + x, REV_V, 16 * wv + 4 * g, old_gv);
                 f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -913,7 +917,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 {
                     const int p = grp * STG + blk * BLK + x;
                     float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-                    emit(2, rs_gv, ogv, p, REV_V, 16 * wv + 4 * g, o, old_gv);
+                    emit(2, rs_gv, p, REV_V, 16 * wv + 4 * g, o, old_gv);
                 }
             }
             if (grp > 0) copy_gy(grp - 1);                     // (uses cvp = v of stage s-1, before copy_v replaces it)

@@ -41,6 +41,12 @@ __device__ __forceinline__ float4 buf_load16f(rsrc_t r, unsigned off)
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ void buf_store16f(rsrc_t r, unsigned off, const float (&v)[4])
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                           r, (int)off, 0, 0);
+}
 __device__ __forceinline__ void buf_store8(rsrc_t r, unsigned off, uint2 v)
 {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
