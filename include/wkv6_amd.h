@@ -215,8 +215,9 @@ int wkv6_sqrelu_backward(long n, const void* x, const void* dout, void* dx, void
 int wkv6_sigmul_forward(long n, const void* r, const void* kv, void* out, void* stream);
 int wkv6_sigmul_backward(long n, const void* r, const void* kv, const void* dout, void* dr, void* dkv, void* stream);
 
-/* Device self-test: the cross-lane primitives, then the chunked MFMA kernels against the exact scan kernels on a fixed
- * pseudo-random problem (forward and backward, all outputs within 2 bf16 ulps of the tensor scale, 4 for gw).
+/* Device self-test: the cross-lane primitives, then the chunked MFMA kernels against the exact scan kernels on two fixed
+ * pseudo-random problems -- one small enough that two workgroups serve a (batch, head) pair, one with one workgroup per pair, so
+ * that both backward kernels run -- (forward and backward, all outputs within 2 bf16 ulps of the tensor scale, 4 for gw).
  * Returns 0 when it passes, WKV6_ESELFTEST (or the number of failed primitive checks) otherwise. */
 int wkv6_selftest(void* stream);
 /* "major.minor" of the library. */

@@ -755,26 +755,10 @@ int rwkv6_cuda_forward_fp32(int B, int T, int C, int H, float* state, const floa
     return rwkv6_infer(B, T, C, H, state, r, k, v, w, u, y, IO_F32, stream);
 }
 
-// Device self-test: (1) the cross-lane primitives, (2) the chunked MFMA kernels against the exact scan kernels on a
-// fixed pseudo-random problem (B=2, T=83, H=2: ragged last block and stage) -- catches a miscompiled or mis-scheduled
-// build (e.g. the mixed-shape MFMA accumulation hazard, DESIGN.md 4.2) at load time instead of in training.
-// Returns 0, a positive count of failed primitive checks, or WKV6_ESELFTEST.
-int wkv6_selftest(void* stream)
+static int selftest_problem(int B, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    {
-        int* d = nullptr;
-        if (hipMalloc(&d, sizeof(int)) != hipSuccess) return WKV6_EWORKSPACE;
-        int host = -1;
-        hipError_t e = hipMemsetAsync(d, 0, sizeof(int), st);
-        if (e == hipSuccess) e = launch_selftest(d, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(&host, d, sizeof(int), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        (void)hipFree(d);
-        if (e != hipSuccess) return (int)e;
-        if (host != 0) return host;
-    }
-    const int B = 2, T = 83, H = 2, C = H * HEAD;
+    const int T = 83, H = 2, C = H * HEAD;
     const size_t n = (size_t)B * T * C, nu = (size_t)C, ngu = (size_t)B * C;
     const size_t ws = wkv6_backward_workspace_bytes(B, T, C, H);
     // layout of one device allocation (bf16 elements): r k v w gy | y[2] gr[2] gk[2] gv[2] gw[2] | u | gu[2] ; then workspace
@@ -830,6 +814,36 @@ int wkv6_selftest(void* stream)
     bad += differ(13 * n, 14 * n, n, 4.f);        // gw
     bad += differ(15 * n + nu, 15 * n + nu + ngu, ngu, 2.f);   // gu
     return bad ? WKV6_ESELFTEST : WKV6_OK;
+}
+
+// Device self-test: (1) the cross-lane primitives, (2) the chunked MFMA kernels against the exact scan kernels on a
+// fixed pseudo-random problem (B=2, T=83, H=2: ragged last block and stage) -- catches a miscompiled or mis-scheduled
+// build (e.g. the mixed-shape MFMA accumulation hazard, DESIGN.md 4.2) at load time instead of in training.
+// Returns 0, a positive count of failed primitive checks, or WKV6_ESELFTEST.
+int wkv6_selftest(void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    {
+        int* d = nullptr;
+        if (hipMalloc(&d, sizeof(int)) != hipSuccess) return WKV6_EWORKSPACE;
+        int host = -1;
+        hipError_t e = hipMemsetAsync(d, 0, sizeof(int), st);
+        if (e == hipSuccess) e = launch_selftest(d, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&host, d, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d);
+        if (e != hipSuccess) return (int)e;
+        if (host != 0) return host;
+    }
+    // two problems of T = 83 tokens (ragged last block and stage, an odd and an even stage of a 64-token pair), H = 2: B = 2 -- few
+    // (batch, head) pairs: the launchers put two workgroups on each (wkv6_chunk_bwd12.hip, 32-token checkpoints) -- and the smallest B
+    // that gets one workgroup per pair on this device (wkv6_chunk_bwd12k.hip, 64-token row-order checkpoints: the default of real shapes)
+    const int cus = cu_count();
+    const int batches[2] = {2, (cus > 0 ? cus : 256) / 4 + 1};
+    for (int prob = 0; prob < 2; ++prob) {
+        if (int rc = selftest_problem(batches[prob], stream)) return rc;
+    }
+    return WKV6_OK;
 }
 
 }  // extern "C"
