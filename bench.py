@@ -407,7 +407,7 @@ def main():
         units = tokens * C                                    # token-channels per step per GPU
         dom_name, dom_ms, dom_b = ("backward", bwd_ms, BWD_BYTES) if bwd_ms >= fwd_ms else ("forward", fwd_ms, FWD_BYTES)
         dom_kernel = "chunk_fwd_kernel" if dom_name == "forward" else \
-            {"64": "chunk_bwd64_kernel", "32": "chunk_bwd12_kernel", "12": "chunk_bwd12_kernel"}.get(os.environ.get("WKV6_BWD", ""),
+            {"64": "chunk_bwd64_kernel"}.get(os.environ.get("WKV6_BWD", ""),
                                                                                                   "chunk_bwd12k_kernel")
         ach = units * dom_b / (dom_ms * 1e-3) / 1e9
 

@@ -836,8 +836,8 @@ int wkv6_selftest(void* stream)
         if (host != 0) return host;
     }
     // two problems of T = 83 tokens (ragged last block and stage, an odd and an even stage of a 64-token pair), H = 2: B = 2 -- few
-    // (batch, head) pairs: the launchers put two workgroups on each (wkv6_chunk_bwd12.hip, 32-token checkpoints) -- and the smallest B
-    // that gets one workgroup per pair on this device (wkv6_chunk_bwd12k.hip, 64-token row-order checkpoints: the default of real shapes)
+    // (batch, head) pairs: the launchers put two workgroups on each -- and the smallest B
+    // that gets one workgroup per pair on this device (the mode of real shapes): both modes of wkv6_chunk_bwd12k.hip run
     const int cus = cu_count();
     const int batches[2] = {2, (cus > 0 ? cus : 256) / 4 + 1};
     for (int prob = 0; prob < 2; ++prob) {

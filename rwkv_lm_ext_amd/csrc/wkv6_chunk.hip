@@ -545,7 +545,7 @@ template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false> hipError_t lau
 // per-lane byte offsets are 32-bit: bf16 tensors need (T + 64) C < 2^31 (checked by the API), the fp32 decay input half of that
 static bool offsets_fit(const ScanArgs& a) { return a.wkind == 1 || ((long)a.T + 64) * a.C < (1L << 30); }
 
-int want_split(int BH);     // wkv6_chunk_bwd12.hip
+int want_split(int BH);     // wkv6_chunk_bwd12k.hip
 
 hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
 {

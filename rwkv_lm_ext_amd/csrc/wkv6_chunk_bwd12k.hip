@@ -1,5 +1,5 @@
 // Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O): 12-wave staged kernel over 64-token checkpoints (the default backward).
-// Companion of wkv6_chunk.hip; wkv6_chunk_bwd12.hip is its 32-token-checkpoint sibling for launches with two workgroups per (batch, head).
+// Companion of wkv6_chunk.hip.
 //
 // Per 16-token block (a = query token, b = key token, c_a exclusive cumulative log decay, S = forward state at
 // block entry, G = dL/d(state after the block)), with Rhat_a = r_a e^{c_a - c_8}, Khat_b = k_b e^{c_8 - c_{b+1}},
@@ -36,8 +36,7 @@
 //   * tiles that every wave of a role needs alike -- dA in both orientations, the masked scores -- are made once per workgroup (row
 //     waves 2, 3 and 0, 1) and handed over as MFMA fragments; the waves of a workgroup are not synchronised inside a stage, so every
 //     hand-over carries a tag (stage index + 1) its readers poll (XT_OFF, xflag below).
-// Launches that split a (batch, head) pair over two workgroups (ScanArgs::split) stay with wkv6_chunk_bwd12.hip and its 32-token
-// checkpoints: the row and column roles cannot share LDS there.
+// Launches with few (batch, head) pairs put the row role and the column role of a pair on two CUs (template parameter SPLIT below).
 #include <type_traits>
 #include "wkv6_chunk.h"
 
@@ -112,13 +111,20 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 // every store.
 // (The kernel proper is a device function of (arguments, workgroup slot) so that chunk_bwd12k_pair_kernel can run it on one of two
 // argument blocks: SURVEY.md row n2.)
-template <bool W_RAW, int GEN>
+// SPLIT (ScanArgs::split: few (batch, head) pairs, B*H <= half the CUs): the row role and the column role run as two 8-wave workgroups
+// on two CUs, each with its own four producers (duplicated preparation on CUs that would otherwise idle); hardware wave w of
+// workgroup part p plays wave w (p = 0: row role) / 4 + w (p = 1: column role) for w < 4 and producer 8 + (w - 4) for w >= 4.  The
+// roles cannot share LDS there: G is kept in both orientations (by rows in the row workgroup for gk, by columns in the column
+// workgroup for gv: no published operand), the producers copy v and gy themselves, and the column waves make their own score
+// tiles.  Every wave does the same arithmetic as in the one-workgroup launch: the outputs are bit-identical.
+template <bool W_RAW, int GEN, bool SPLIT>
 __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][RBLK_BYTES] | [3][SBLK][KBLK_BYTES] | tiles | G operand
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = (int)slot;
+    const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = SPLIT ? (int)(slot & 1) : 0, bh = SPLIT ? (int)(slot >> 1) : (int)slot;
+    const int wid = SPLIT ? (hwid < 4 ? hwid + 4 * part : hwid + 4) : hwid;
     const bool rowrole = wid < 4, producer = wid >= 8;
     const int wv = wid & 3;                                              // tile owned by a row / column wave
     const int pb = wid & 1, half = (wid >> 1) & 1;                       // producer: block of the stage, channel half
@@ -197,6 +203,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     uint2 nr[2], nk[2], nw[2];
     float4 ne[2];
     uint2 ck_[2];
+    uint2 nv[2], ng[2], pv[2], pg[2], cv_[2];                         // SPLIT: the producers also move v (K part) and gy (R part)
     float cfr[2][4], clw[2][4], cc8[4] = {0.f, 0.f, 0.f, 0.f};
     const rsrc_t rs_r = make_rsrc(gr_, nbytes), rs_k = make_rsrc(gk_, nbytes), rs_v = make_rsrc(gv_, nbytes), rs_g = make_rsrc(ggy, nbytes);
     const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, nbytes)
@@ -206,6 +213,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         for (int tt = 0; tt < 2; ++tt) {
             const int p = stg * STG + pb * BLK + 2 * tq + tt;
             nr[tt] = buf_load8(rs_r, (unsigned)(tokmap(p, REV_R) * a.C + ch0) * 2u);
+            if constexpr (SPLIT) ng[tt] = buf_load8(rs_g, (unsigned)(tokmap(p, REV_Y) * a.C + ch0) * 2u);
         }
     };
     auto load_kw = [&](int stg) {
@@ -214,6 +222,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             const int p = stg * STG + pb * BLK + 2 * tq + tt;
             const unsigned ik = (unsigned)(tokmap(p, REV_K) * a.C + ch0), iw = (unsigned)(tokmap(p, REV_W) * a.C + ch0);
             nk[tt] = buf_load8(rs_k, ik * 2u);
+            if constexpr (SPLIT) nv[tt] = buf_load8(rs_v, (unsigned)(tokmap(p, REV_V) * a.C + ch0) * 2u);
             if constexpr (W_RAW) nw[tt] = buf_load8(rs_w, iw * 2u);
             else ne[tt] = buf_load16f(rs_w, iw * 4u);
         }
@@ -221,15 +230,21 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // the loaded set becomes the working set (register moves: the next loads may then overwrite n*)
     auto take_r = [&]() {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) pr[tt] = nr[tt];
+        for (int tt = 0; tt < 2; ++tt) {
+            pr[tt] = nr[tt];
+            if constexpr (SPLIT) pg[tt] = ng[tt];
+        }
         asm volatile("" : "+v"(pr[0].x), "+v"(pr[0].y), "+v"(pr[1].x), "+v"(pr[1].y));
+        if constexpr (SPLIT) asm volatile("" : "+v"(pg[0].x), "+v"(pg[0].y), "+v"(pg[1].x), "+v"(pg[1].y));
     };
     auto take_kw = [&]() {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             pk[tt] = nk[tt];
+            if constexpr (SPLIT) pv[tt] = nv[tt];
             if constexpr (W_RAW) pw[tt] = nw[tt]; else pe[tt] = ne[tt];
         }
+        if constexpr (SPLIT) asm volatile("" : "+v"(pv[0].x), "+v"(pv[0].y), "+v"(pv[1].x), "+v"(pv[1].y));
         if constexpr (W_RAW)
             asm volatile("" : "+v"(pk[0].x), "+v"(pk[0].y), "+v"(pk[1].x), "+v"(pk[1].y), "+v"(pw[0].x), "+v"(pw[0].y), "+v"(pw[1].x), "+v"(pw[1].y));
         else
@@ -269,6 +284,18 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 *reinterpret_cast<uint2*>(rowz + R_R * ARR) = pr[tt];
                 *reinterpret_cast<uint2*>(rowz + R_K * ARR) = ck_[tt];
                 *reinterpret_cast<float4*>(rb + ROFF_LW + tok * FRS + ch0 * 4) = make_float4(clw[tt][0], clw[tt][1], clw[tt][2], clw[tt][3]);
+                if constexpr (SPLIT) {
+                    // gy of the stage into its R part, and vg_a = gy_a . v_a over this half's 32 channels with the v the stage's K part
+                    // left in cv_ (exact bf16 products, fp32 sums: the same half sums the column waves form in the one-workgroup launch)
+                    *reinterpret_cast<uint2*>(rb + tok * RSB + ch0 * 2 + R_GY * ARR) = pg[tt];
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    float pvg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pg[tt].x), __builtin_bit_cast(bf2, cv_[tt].x), 0.f, false);
+                    pvg = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pg[tt].y), __builtin_bit_cast(bf2, cv_[tt].y), pvg, false);
+                    pvg += dpp_mov<DPP_XOR1>(pvg);
+                    pvg += dpp_mov<DPP_XOR2>(pvg);
+                    pvg += dpp_mov<DPP_SHL4>(pvg);
+                    if (c8i == 0) *reinterpret_cast<float*>(rb + ROFF_VG + (half * 16 + tok) * 4) = pvg;
+                }
             }
         }
         // ---- K, first half: log-decays of the stage's tokens, their sums inside the lane, the gw multipliers
@@ -278,6 +305,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 const bool valid = sk * STG + pb * BLK + 2 * tq + tt < ntok;
                 k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
                 ck_[tt] = pk[tt];
+                if constexpr (SPLIT) {
+                    *reinterpret_cast<uint2*>(kb + (2 * tq + tt) * RSB + ch0 * 2 + K_V * ARR) = pv[tt];
+                    cv_[tt] = pv[tt];
+                }
                 float lw[4];
                 if constexpr (W_RAW) {
                     lw[0] = -exp2_fast(LOG2E * bf_lo(pw[tt].x)); lw[1] = -exp2_fast(LOG2E * bf_hi(pw[tt].x));
@@ -496,7 +527,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         // ST[blk][jt][q] = S_entry(blk)[i = 16wv + x][j = tile_ch(jt) + 8g + q]   (transposed tiles: lane = key row)
         float ue[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 16 * wv + 4 * g, ue);
-        f4v ST[SBLK][4];
+        // GI[jt][q]      = G[i = 16wv + x][j = tile_ch(jt) + 8g + q]                  (SPLIT only: the adjoint state by rows)
+        f4v ST[SBLK][4], GI[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) GI[t] = f4v{0.f, 0.f, 0.f, 0.f};
         float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.rc_in) io4<float>::load(a.rc_in + (long)b * a.C + h * HEAD + 16 * wv + 4 * g, Rc);   // the suffix sum beyond this segment
         // Checkpoint of the 64-token pair that holds stage `stg`: the forward wrote it in this wave's register order
@@ -568,7 +602,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 split4(dba, th, tl);
                 tile_store(XT_OFF + (2 * tb + 1) * 1024, th, tl);
                 publish(TAG_DA + 2 * tb + 1, grp + 1);
-            } else {         // row waves 0 and 1: the masked score tile of block wv, for the column waves
+            } else if constexpr (!SPLIT) {   // row waves 0 and 1: the masked score tile of block wv, for the column waves
                 const char* const rb = rpart(grp, wv);
                 const char* const kb = kpart(grp, wv);
                 f4v sc = {0.f, 0.f, 0.f, 0.f};
@@ -628,10 +662,12 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 }
                 return acc;
             };
-            await4(TAG_GA, grp + 1);
-            gvb[1] = take_gop(1);
-            asm volatile("" :: "v"(gvb[1]));                   // (the operand reads have returned)
-            publish(TAG_GB + wv, grp + 1);
+            if constexpr (!SPLIT) {
+                await4(TAG_GA, grp + 1);
+                gvb[1] = take_gop(1);
+                asm volatile("" :: "v"(gvb[1]));               // (the operand reads have returned)
+                publish(TAG_GB + wv, grp + 1);
+            }
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
             f4v ackp[SBLK];
@@ -704,8 +740,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             WKV6_T(ts3);
             // the next stage's checkpoint: the state registers of this stage are dead from here on
             if (grp > 0) request_ckpt(grp - 1);
-            await4(TAG_GC, grp + 1);
-            gvb[0] = take_gop(0);
+            if constexpr (!SPLIT) {
+                await4(TAG_GC, grp + 1);
+                gvb[0] = take_gop(0);
+            }
             // ---- chain: only the work that needs G
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
@@ -714,7 +752,38 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 float old_gk[4] = {0.f, 0.f, 0.f, 0.f}, old_gw[4] = {0.f, 0.f, 0.f, 0.f};
                 fetch_old(1, rs_gk, grp * STG + blk * BLK + x, REV_K, 16 * wv + 4 * g, old_gk);
                 fetch_old(3, rs_gw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw);
-                f4v acck = gvb[blk];
+                f4v acck = {0.f, 0.f, 0.f, 0.f};
+                [[maybe_unused]] f4v Oi[4];
+                [[maybe_unused]] float e8x = 0.f, e16x = 0.f;
+                if constexpr (SPLIT) {
+                    // the G-dependent part of gk from this workgroup's own copy of G (by rows), and the (gy^T Rhat) tiles of its update
+                    e8x = *reinterpret_cast<const float*>(rb + ROFF_E8 + (16 * wv + x) * 4);
+                    e16x = *reinterpret_cast<const float*>(kb + KOFF_E16 + (16 * wv + x) * 4);
+                    const float e16m8x = *reinterpret_cast<const float*>(kb + KOFF_E16M8 + (16 * wv + x) * 4);
+                    const s4v rhf_w = tr_read(rb + R_RH * ARR + troff + 32 * wv);  // Rhat[4g+e][16wv + x]
+                    const s4v rlf_w = tr_read(rb + R_RL * ARR + troff + 32 * wv);
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {             // [row j_local][col i_local = x]
+                        const s4v gyf = tr_read(rb + R_GY * ARR + trow + tile_tr(jt));
+                        f4v o = {0.f, 0.f, 0.f, 0.f};
+                        o = mfma16(gyf, rhf_w, o);
+                        o = mfma16(gyf, rlf_w, o);
+                        Oi[jt] = o;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const b8v vr = ld_b8(kb + K_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
+                        float t0[4], t1[4];
+                        b8v hi, lo;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
+                        split8(t0, t1, hi, lo);
+                        acck = mfma32(hi, vr, acck);
+                        acck = mfma32(lo, vr, acck);
+                    }
+                } else {
+                    acck = gvb[blk];
+                }
                 acck += ackp[blk];
                 {
                     const int ch = 16 * wv + 4 * g;
@@ -750,6 +819,13 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     const int p = grp * STG + blk * BLK + x;
                     emit(1, rs_gk, p, REV_K, ch, o_gk, old_gk);
                     emit(3, rs_gw, p, REV_W, ch, o_gw, old_gw);
+                }
+                // ---- (SPLIT) G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * Oi[jt][q]);
                 }
             }
             WKV6_T(ts4);
@@ -819,7 +895,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 if ((cl & 7) == 0) *reinterpret_cast<float*>(rb + ROFF_VG + ((cl >> 3) * 16 + tok) * 4) = vg;
             }
         };
-        if (ngrp > 0) {
+        if (!SPLIT && ngrp > 0) {                                  // (SPLIT: the producers of this workgroup move v and gy)
             load_v(ngrp - 1);
             load_gy(ngrp - 1);
             copy_v(ngrp - 1);
@@ -832,14 +908,16 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             WKV6_T(ts0);
-            if (grp > 0) load_gy(grp - 1);
-            if (grp > 1) load_v(grp - 2);
+            if (!SPLIT && grp > 0) load_gy(grp - 1);
+            if (!SPLIT && grp > 1) load_v(grp - 2);
             // ---- the stage's G recurrence, first thing: per block (1, then 0) scale by E16m8, split, publish the operand for the row
             // waves (stored [j][i]: this lane's 16 bytes are key rows 32s + 8g .. +7 of value column 16wv + x), keep the fragments for
             // this wave's own chain, and move G to the entry of the block
             s4v gyT_w[SBLK], sc_hi[SBLK], sc_lo[SBLK];
             f4v accp[SBLK];
             b8v gh[SBLK][2], gl[SBLK][2];
+            [[maybe_unused]] f4v Og[SBLK][4];
+            if constexpr (!SPLIT)
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const rb = rpart(grp, blk);
@@ -881,6 +959,33 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 }
             }
             // ---- pre-phase: everything that does not depend on G
+            if (SPLIT && wv < SBLK) {   // (no row waves in this workgroup) this wave's score tile of the stage: block wv
+                const char* const rb = rpart(grp, wv);
+                const char* const kb = kpart(grp, wv);
+                f4v sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int off = x * RSB + (32 * s + 8 * g) * 2;
+                    const b8v rh = ld_b8(rb + R_RH * ARR + off), rl = ld_b8(rb + R_RL * ARR + off);
+                    const b8v kh = ld_b8(kb + K_KH * ARR + off), kl = ld_b8(kb + K_KL * ARR + off);
+                    sc = mfma32(rh, kh, sc);                  // A[row a][col b]: lane col b = x, rows a = 4g+q
+                    sc = mfma32(rh, kl, sc);
+                    sc = mfma32(rl, kh, sc);
+                }
+                const float4 cfa = *reinterpret_cast<const float4*>(rb + ROFF_COEF + 16 * g);
+                const float4 cfb = *reinterpret_cast<const float4*>(rb + ROFF_COEF + 64 + 16 * g);
+                const float cf[4] = {cfa.x + cfb.x, cfa.y + cfb.y, cfa.z + cfb.z, cfa.w + cfb.w};
+                float scm[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 4 * g + q;                  // query token a; key token b = x
+                    scm[q] = x < o ? sc[q] : (x == o ? cf[q] : 0.f);
+                }
+                uint2 th, tl;
+                split4(scm, th, tl);
+                tile_store(XS_OFF + wv * 1024, th, tl);
+                publish(TAG_SC + wv, grp + 1);
+            }
 #pragma unroll
             for (int blk = 0; blk < SBLK; ++blk) gyT_w[blk] = tr_read(rpart(grp, blk) + R_GY * ARR + troff + 32 * wv);   // gy[4g+e][16wv + x]
 #pragma unroll
@@ -896,6 +1001,18 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 acc = mfma16(gyT_w[blk], sc_hi[blk], acc);
                 acc = mfma16(gyT_w[blk], sc_lo[blk], acc);
                 accp[blk] = acc;
+                if constexpr (SPLIT) {
+                    const char* const rb = rpart(grp, blk);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {              // (Rhat^T gy) tile: [row i_local][col j_local = x]
+                        const s4v rhf = tr_read(rb + R_RH * ARR + trow + tile_tr(it));
+                        const s4v rlf = tr_read(rb + R_RL * ARR + trow + tile_tr(it));
+                        f4v o = {0.f, 0.f, 0.f, 0.f};
+                        o = mfma16(rhf, gyT_w[blk], o);
+                        o = mfma16(rlf, gyT_w[blk], o);
+                        Og[blk][it] = o;
+                    }
+                }
             }
             WKV6_T(ts1);
             // ---- chain: only the work that needs G
@@ -909,6 +1026,15 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 for (int s = 0; s < 2; ++s) {
                     const int off = x * RSB + (32 * s + 8 * g) * 2;
                     const b8v kh = ld_b8(kb + K_KH * ARR + off), kl = ld_b8(kb + K_KL * ARR + off);
+                    if constexpr (SPLIT) {                     // this workgroup's own G recurrence runs here, in the chain
+                        float t0[4], t1[4];
+                        const float4 m0 = *reinterpret_cast<const float4*>(kb + KOFF_E16M8 + (32 * s + 8 * g) * 4);
+                        const float4 m1 = *reinterpret_cast<const float4*>(kb + KOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
+                        t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
+                        t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
+                        t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
+                        split8(t0, t1, gh[blk][s], gl[blk][s]);
+                    }
                     acc = mfma32(gh[blk][s], kh, acc);       // k-slot (s, g, e) <-> key channel 32s + 8g + e
                     acc = mfma32(gh[blk][s], kl, acc);
                     acc = mfma32(gl[blk][s], kh, acc);
@@ -919,9 +1045,22 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     float o[4] = {acc[0], acc[1], acc[2], acc[3]};
                     emit(2, rs_gv, p, REV_V, 16 * wv + 4 * g, o, old_gv);
                 }
+                // ---- (SPLIT) G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
+                if constexpr (SPLIT) {
+                    const char* const rb = rpart(grp, blk);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const float4 d16 = *reinterpret_cast<const float4*>(kb + KOFF_E16 + (tile_ch(it) + 8 * g) * 4);
+                        const float4 d8 = *reinterpret_cast<const float4*>(rb + ROFF_E8 + (tile_ch(it) + 8 * g) * 4);
+                        GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * Og[blk][it][0]);
+                        GJ[it][1] = fmaf(d16.y, GJ[it][1], d8.y * Og[blk][it][1]);
+                        GJ[it][2] = fmaf(d16.z, GJ[it][2], d8.z * Og[blk][it][2]);
+                        GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * Og[blk][it][3]);
+                    }
+                }
             }
-            if (grp > 0) copy_gy(grp - 1);                     // (uses cvp = v of stage s-1, before copy_v replaces it)
-            if (grp > 1) copy_v(grp - 2);
+            if (!SPLIT && grp > 0) copy_gy(grp - 1);           // (uses cvp = v of stage s-1, before copy_v replaces it)
+            if (!SPLIT && grp > 1) copy_v(grp - 2);
             WKV6_T(ts2);
             __syncthreads();
             WKV6_T(ts3);
@@ -948,7 +1087,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         d[7] = rtc1 - rtc0;
     }
 #endif
-    if (GEN == 1 && a.zero_tail) {
+    if (GEN == 1 && a.zero_tail && part == 0) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += (int)(blockDim.x >> 4)) {
             const unsigned idx = (unsigned)(t * a.C + 4 * (tid & 15));
@@ -960,10 +1099,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     }
 }
 
-template <bool W_RAW, int GEN>
+template <bool W_RAW, int GEN, bool SPLIT>
 __global__ __launch_bounds__(768) void chunk_bwd12k_kernel(const ScanArgs a)
 {
-    chunk_bwd12k_body<W_RAW, GEN>(a, blockIdx.x);
+    chunk_bwd12k_body<W_RAW, GEN, SPLIT>(a, blockIdx.x);
 }
 
 // the backward of chunk_fwd_pair_kernel (wkv6_chunk.hip): two problems of one shape, slots [0, B H) serve a0, the rest a1
@@ -972,15 +1111,20 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_pair_kernel(const ScanArgs a
 {
     const unsigned n = (unsigned)(a0.B * a0.H);
     const bool second = blockIdx.x >= n;
-    chunk_bwd12k_body<W_RAW, 0>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);
+    chunk_bwd12k_body<W_RAW, 0, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);
 }
 
 template <bool W_RAW, int GEN> hipError_t launch_bwd12k_inst(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = BWD12K_LDS;
-    static LdsAttrOnce attr;                   // per instantiation and device
-    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12k_kernel<W_RAW, GEN>), lds)) return e;
-    hipLaunchKernelGGL((chunk_bwd12k_kernel<W_RAW, GEN>), dim3(a.B * a.H), dim3(768), lds, st, a);
+    static LdsAttrOnce attr, attr_split;       // per instantiation and device
+    if (a.split) {
+        if (hipError_t e = attr_split.ensure(reinterpret_cast<const void*>(chunk_bwd12k_kernel<W_RAW, GEN, true>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_kernel<W_RAW, GEN, true>), dim3(2 * a.B * a.H), dim3(512), lds, st, a);
+    } else {
+        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12k_kernel<W_RAW, GEN, false>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_kernel<W_RAW, GEN, false>), dim3(a.B * a.H), dim3(768), lds, st, a);
+    }
     return hipGetLastError();
 }
 template <bool W_RAW> hipError_t launch_bwd12k_variant(const ScanArgs& a, hipStream_t st)
@@ -992,10 +1136,46 @@ template <bool W_RAW> hipError_t launch_bwd12k_variant(const ScanArgs& a, hipStr
 
 }  // namespace
 
-// reverse pass over 64-token row-order checkpoints (a.ckpt filled by the forward or by launch_chunk_state_pass); unsplit launches only
+hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // wkv6_chunk.hip
+
+// two workgroups per (batch, head) when one each would leave at least half of the CUs without work
+int cu_count()              // compute units of the current device (0: unknown)
+{
+    static int cus[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus[dev] = prop.multiProcessorCount;
+    }
+    return cus[dev];
+}
+int want_split(int BH)
+{
+    if (const char* e = getenv("WKV6_SPLIT")) return atoi(e) != 0;     // A/B switch
+    return 2 * BH <= cu_count();
+}
+
+// Which chunked backward serves a call, hence how far apart the forward's checkpoints are and how one is laid out (wkv6_scan.h).
+// Default: this file's kernel over 64-token checkpoints in row-wave order, with one or two workgroups per (batch, head).  The one
+// switch left, read per call (a backward that is told its checkpoints are valid checks what the forward noted for that buffer:
+// wkv6_api.hip, ckpt_note): WKV6_BWD=64 -- the two-level 16-wave experiment wkv6_chunk_bwd64.hip (64-token checkpoints in forward
+// order, one workgroup per pair only; profiles/r03_bwd64_*).  (Round 3's 32-token kernel, wkv6_chunk_bwd12.hip, was retired in
+// round 4 once this kernel had taken over its two-workgroup mode: profiles/r04_ck64_*, r04_split_mode_ab.txt have the A/B numbers.)
+CkptPlan chunk_ckpt_plan(int BH)
+{
+    if (const char* e = getenv("WKV6_BWD")) {
+        if (atoi(e) == 64 && !want_split(BH)) return CkptPlan{64, CKPT_FWD_ORDER};
+    }
+    return CkptPlan{CKT, CKPT_ROW_ORDER};
+}
+
+// reverse pass over 64-token row-order checkpoints (a.ckpt filled by the forward or by launch_chunk_state_pass); a.split as given
 hipError_t launch_chunk_bwd12k(const ScanArgs& a_, hipStream_t st)
 {
-    if (a_.ckpt_tok != CKT || a_.ckpt_fmt != CKPT_ROW_ORDER || a_.split || !a_.ckpt) return hipErrorInvalidValue;
+    if (a_.ckpt_tok != CKT || a_.ckpt_fmt != CKPT_ROW_ORDER || !a_.ckpt) return hipErrorInvalidValue;
+    if (a_.split && (a_.g_in || a_.rc_in)) return hipErrorInvalidValue;     // (segment rows of a two-level scan run one workgroup each)
 #ifdef WKV6_DEBUGBUF
     ScanArgs a = a_;
     a.aux = reinterpret_cast<float*>(g_stamp_buffer);
@@ -1005,8 +1185,41 @@ hipError_t launch_chunk_bwd12k(const ScanArgs& a_, hipStream_t st)
     return a.wkind ? launch_bwd12k_variant<true>(a, st) : launch_bwd12k_variant<false>(a, st);
 }
 
-hipError_t launch_chunk_bwd12k_pair(const ScanArgs& a0, const ScanArgs& a1, hipStream_t st)
+hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)
 {
+    ScanArgs a = a_;
+    if (a.ckpt_tok != 64) return hipErrorInvalidValue;
+    a.split = a.ckpt_fmt == CKPT_ROW_ORDER ? want_split(a.B * a.H) : 0;
+    if (a.wkind != 1 && ((long)a.T + 64) * a.C >= (1L << 30)) return hipErrorInvalidValue;   // 32-bit byte offsets of the fp32 decay input
+    if (!a.ckpt_valid) {                   // self-contained backward: state pass first (same inputs, no outputs)
+        ScanArgs sp = a;
+        sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
+        if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
+    }
+    if (a.ckpt_fmt == CKPT_ROW_ORDER) return launch_chunk_bwd12k(a, st);
+    return launch_chunk_bwd64(a, st);
+}
+
+// Backward of both problems of a bidirectional composition in one launch; both checkpoint sets must come from the forward
+// (ckpt_valid).  Two launches where a (batch, head) pair is split over two workgroups or the two-level kernel is selected.
+hipError_t launch_chunk_bwd_pair(const ScanArgs& a0_, const ScanArgs& a1_, hipStream_t st)
+{
+    if (a0_.B != a1_.B || a0_.T != a1_.T || a0_.C != a1_.C || a0_.H != a1_.H || a0_.wkind != a1_.wkind) return hipErrorInvalidValue;
+    const auto plain = [](const ScanArgs& a) {
+        return !a.accumulate && !a.zero_tail && !a.g_f32[0] && !a.g_f32[1] && !a.g_f32[2] && !a.g_f32[3] && a.ckpt && a.ckpt_valid;
+    };
+    if (!plain(a0_) || !plain(a1_)) return hipErrorNotSupported;
+    const bool rowfmt = a0_.ckpt_fmt == CKPT_ROW_ORDER && a1_.ckpt_fmt == CKPT_ROW_ORDER && a0_.ckpt_tok == CKT && a1_.ckpt_tok == CKT;
+    if (!rowfmt || want_split(a0_.B * a0_.H)) {
+        if (hipError_t e = launch_chunk_bwd(a0_, st)) return e;
+        return launch_chunk_bwd(a1_, st);
+    }
+    if (a0_.wkind != 1 && ((long)a0_.T + 64) * a0_.C >= (1L << 30)) return hipErrorInvalidValue;
+    ScanArgs a0 = a0_, a1 = a1_;
+    a0.split = a1.split = 0;
+#ifdef WKV6_DEBUGBUF
+    a0.aux = a1.aux = reinterpret_cast<float*>(g_stamp_buffer);
+#endif
     constexpr size_t lds = BWD12K_LDS;
     static LdsAttrOnce attr_raw, attr_ew;
     if (a0.wkind == 1) {

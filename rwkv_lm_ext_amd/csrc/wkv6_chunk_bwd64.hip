@@ -1,6 +1,6 @@
 // Chunked MFMA backward of WKV6 for gfx950 (bf16 I/O), two-level form: 64-token chunks, 16-token blocks, 16 identical waves.
 //
-// Why a second backward (the 12-wave staged kernel is wkv6_chunk_bwd12.hip): that kernel touches, scales, splits and updates
+// Why a second backward (the 12-wave staged kernel is wkv6_chunk_bwd12k.hip): that kernel touches, scales, splits and updates
 // three 64x64 state copies every 16 tokens, needs a forward-state checkpoint every 32 tokens (8 B of HBM per token-channel) and
 // gives each of its three roles ONE wave per SIMD, so every role runs at the latency of a single instruction stream
 // (profiles/r03_clock_and_roles.txt: each role alone takes 0.19-0.27 ms of the 0.47 ms).  Here
@@ -70,7 +70,7 @@ constexpr int L_VG = L_RCX + 1024;                     // float [64]     gy.v pe
 constexpr int BWD64_LDS = L_VG + 256;
 static_assert(BWD64_LDS <= 160 * 1024, "LDS budget");
 
-// four independent in-row scans, one step (see wkv6_chunk_bwd12.hip for the wait-state reasoning)
+// four independent in-row scans, one step (see wkv6_chunk_bwd12k.hip for the wait-state reasoning)
 #define WKV6_DPP_STEP4(x, ctrl) asm("s_nop 1\n\t" \
     "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
     "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf" \
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) void chunk_bwd64_kernel(const ScanArgs a)
     const RevMap tokmap = make_revmap(a, b, ntok);
     const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
     const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);
-    // gradient store of scan position pos, channels ch..ch+3 (same contract as wkv6_chunk_bwd12.hip: emit)
+    // gradient store of scan position pos, channels ch..ch+3 (same contract as wkv6_chunk_bwd12k.hip: emit)
     auto emit = [&](int which, const rsrc_t& rs, bf16_t* out, int pos, unsigned bit, int ch, float (&o)[4]) {
         const unsigned idx = (unsigned)(tokmap(pos, bit) * a.C + ch);
         if constexpr (!GEN) {

@@ -23,17 +23,16 @@
 
 namespace wkv6 {
 
-// The chunked forward leaves fp32 state checkpoints for the chunked backward; which backward kernel serves a call decides how
-// far apart they are and how one 64x64 state is laid out:
-//   * default (one workgroup per (batch, head)): wkv6_chunk_bwd12k.hip -- every 64 tokens (4 B per token-channel), in the register
-//     order of that kernel's row waves (CKPT_ROW_ORDER: [row wave i>>4][column tile jt][lane 16 g + (i & 15)][4 columns
-//     tile_ch(jt) + 8 g + q]), so that a row wave takes its 16x64 slice with four coalesced 16-byte loads;
-//   * two workgroups per (batch, head) (ScanArgs::split, few long sequences): wkv6_chunk_bwd12.hip -- every 32 tokens, in the
-//     forward consumers' register order (CKPT_FWD_ORDER: [consumer wave j>>4][tile it][lane][4 key rows]);
-//   * WKV6_BWD=64: the two-level experiment wkv6_chunk_bwd64.hip -- every 64 tokens, CKPT_FWD_ORDER.
+// The chunked forward leaves fp32 state checkpoints for the chunked backward, one 64x64 state per 64 tokens and head (4 B per
+// token-channel); which backward kernel serves a call decides how one is laid out:
+//   * default: wkv6_chunk_bwd12k.hip -- in the register order of that kernel's row waves (CKPT_ROW_ORDER: [row wave i>>4][column tile jt]
+//     [lane 16 g + (i & 15)][4 columns tile_ch(jt) + 8 g + q]), so that a row wave takes its 16x64 slice with four coalesced 16-byte
+//     loads; with one or two workgroups per (batch, head);
+//   * WKV6_BWD=64: the two-level experiment wkv6_chunk_bwd64.hip -- in the forward consumers' register order (CKPT_FWD_ORDER:
+//     [consumer wave j>>4][tile it][lane][4 key rows]).
 enum { CKPT_FWD_ORDER = 0, CKPT_ROW_ORDER = 1 };
 struct CkptPlan { int tok, fmt; };
-CkptPlan chunk_ckpt_plan(int BH);            // wkv6_chunk_bwd12.hip
+CkptPlan chunk_ckpt_plan(int BH);            // wkv6_chunk_bwd12k.hip
 inline int chunk_ckpt_tok(int BH) { return chunk_ckpt_plan(BH).tok; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute is per device.
@@ -128,11 +127,10 @@ hipError_t launch_chunk_bwd_pair(const ScanArgs& a0, const ScanArgs& a1, hipStre
 // chunked MFMA backward (bf16 I/O only): state pass + reverse pass; a.ckpt must hold chunk_ckpt_floats() floats
 hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st);
 hipError_t launch_chunk_bwd64(const ScanArgs& a, hipStream_t st);     // two-level backward proper (wkv6_chunk_bwd64.hip)
-hipError_t launch_chunk_bwd12k(const ScanArgs& a, hipStream_t st);    // reverse pass over 64-token row-order checkpoints (wkv6_chunk_bwd12k.hip)
-hipError_t launch_chunk_bwd12k_pair(const ScanArgs& a0, const ScanArgs& a1, hipStream_t st);
+hipError_t launch_chunk_bwd12k(const ScanArgs& a, hipStream_t st);    // reverse pass over 64-token row-order checkpoints, a.split as given (wkv6_chunk_bwd12k.hip)
 size_t chunk_ckpt_floats(int B, int T, int H);
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // state recurrence only (s_out, ckpt, dsum)
 int cu_count();
-int want_split(int BH);                      // two workgroups per (batch, head)?  (wkv6_chunk_bwd12.hip)
+int want_split(int BH);                      // two workgroups per (batch, head)?  (wkv6_chunk_bwd12k.hip)
 
 }  // namespace wkv6

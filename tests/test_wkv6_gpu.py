@@ -288,10 +288,9 @@ def test_autograd_surface(ops, oracle):
 
 def test_two_workgroups_per_head_is_the_same_arithmetic(ops, monkeypatch):
     """Few (batch, head) pairs (B*H <= half the CUs) run as two workgroups per pair -- forward: two consumer waves each, backward:
-    row role / column role of the 32-token-checkpoint kernel -- with the same per-wave arithmetic: every output is bit-identical to
-    the one-workgroup launch of the same kernel family (WKV6_BWD=32; WKV6_SPLIT forces either mode; the default picks by grid size,
-    so the suite's small cases run split and the full-size ones not)."""
-    monkeypatch.setenv("WKV6_BWD", "32")
+    row role / column role, each with its own producers and its own copy of G -- with the same per-wave arithmetic: every output is
+    bit-identical to the one-workgroup launch (WKV6_SPLIT forces either mode; the default picks by grid size, so the suite's small
+    cases run split and the full-size ones not)."""
     bf = torch.bfloat16
     B, T, H = 3, 200, 2
     r, k, v, w, u, gy = rand_inputs(11, B, T, H)

@@ -24,6 +24,5 @@ for wl in bi infctx; do
 done
 python3 $ROOT/bench.py --workload prefill --steps 20 --warmup 5 --no-cpu > "$ROOT/$OUT/bench_prefill.json" 2> /dev/null
 WKV6_BWD=64 python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu --traffic none > "$ROOT/$OUT/bench_wkv6_bwd64.json" 2> /dev/null   # the two-level experiment
-WKV6_BWD=32 python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu --traffic none > "$ROOT/$OUT/bench_wkv6_bwd32.json" 2> /dev/null   # 32-token checkpoints (round-3 default)
 python3 $ROOT/bench.py --steps 100 --warmup 20 > "$ROOT/$OUT/bench_wkv6.json" 2> "$ROOT/$OUT/bench_wkv6.err"           # traffic measured live
 echo done

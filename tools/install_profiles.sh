@@ -6,7 +6,6 @@ SRC=$1; R=$2
 python3 tools/aggregate_profiles.py $SRC profiles/${R}_final > /dev/null
 cp $SRC/bench_wkv6.json profiles/${R}_bench_final.json
 for w in bi infctx prefill; do cp $SRC/bench_$w.json profiles/${R}_bench_$w.json; done
-cp $SRC/bench_wkv6_bwd32.json profiles/${R}_bench_bwd32_optin.json
 cp $SRC/bench_wkv6_bwd64.json profiles/${R}_bench_bwd64_optin.json
 for w in bi infctx; do
     f=$(ls -t $SRC/stats_$w/*/*kernel_stats.csv | head -1)
