@@ -79,7 +79,7 @@ constexpr int XFLAG_OFF = 128;                                         // int [6
 // first thing, the row waves need its products last: nobody waits.
 constexpr int GRS = 144;                                               // bytes per row of the published operand
 constexpr int GOP_OFF = XS_OFF + 2 * 1024;                             // bf16 [2 (hi | lo)][64][GRS / 2]
-constexpr int TAG_DA = 0, TAG_SC = 4, TAG_GA = 8, TAG_GB = 12, TAG_GC = 16, N_TAGS = 20;   // tag slots (see xflag)
+constexpr int TAG_DA = 0, TAG_SC = 4, TAG_GA = 8, TAG_GB = 12, TAG_GC = 16, TAG_GD = 20, TAG_GE = 24, TAG_GF = 28, N_TAGS = 32;   // tag slots (see xflag)
 constexpr int BWD12K_LDS = GOP_OFF + 2 * HEAD * GRS;
 static_assert(BWD12K_LDS <= 160 * 1024, "LDS budget");
 
@@ -143,7 +143,11 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const RevMap tokmap = make_revmap(a, b, ntok);
     // buffer resources over this row's first ntok tokens (wkv6_common.h): loads past the end return 0, stores are dropped
+#ifdef WKV6_EXP_NOSTORE                                               // timing-only experiment: every gradient store dropped by the bounds check
+    const unsigned nbytes = 0u;
+#else
     const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
+#endif
     const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);
     // wkv6_bi's halves: the first (GEN == 1) writes its four gradients into fp32 side buffers (or, without them, the outputs), the
     // second (GEN == 2) requests them ahead of the work whose result they meet, adds and rounds once.  Side buffers and outputs alike
@@ -165,22 +169,69 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             }
         }
     };
-    // gradient store of scan position p, channels ch..ch+3
-    auto emit = [&](int which, const rsrc_t& rs, int p, unsigned bit, int ch, float (&o)[4], const float (&old)[4]) {
-        const unsigned idx = (unsigned)(tokmap(p, bit) * a.C + ch);
+#ifdef WKV6_STAMP
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+    [[maybe_unused]] unsigned long long tp0 = 0, tp1 = 0;
+// slot 5 of a wave's record, chosen at build time (-DWKV6_STAMP5=1: cycles inside tag polls; =2: around the issue of vector-memory instructions)
+#ifndef WKV6_STAMP5
+#define WKV6_STAMP5 1
+#endif
+#define WKV6_T5(kind, var) do { if (WKV6_STAMP5 == (kind) || ((kind) == 1 && WKV6_STAMP5 == 3)) WKV6_T(var); } while (0)
+#define WKV6_ACC5(kind, t1, t0) do { if (WKV6_STAMP5 == (kind)) stamp_acc[5] += (t1) - (t0); } while (0)
+    unsigned long long poll_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // cycles inside the polls of each tag group (DA SC GA GB GC GD GE GF)
+#define WKV6_ACCP(idx, t1, t0) do { if (WKV6_STAMP5 == 1 || (WKV6_STAMP5 == 3 && ((idx) >> 2) != 0 && ((idx) >> 2) != 2 && ((idx) >> 2) != 4)) poll_acc[(idx) >> 2] += (t1) - (t0); } while (0)
+#else
+#define WKV6_ACCP(idx, t1, t0) do { } while (0)
+#define WKV6_T5(kind, var) do { } while (0)
+#define WKV6_ACC5(kind, t1, t0) do { } while (0)
+#endif
+    // Gradient stores.  A wave's result tile is 16 tokens x 16 channels -- 32 bytes per token row of the [B, T, C] tensors -- and the
+    // memory pipeline takes stores of such pieces badly: tools/microbench/head_slices.hip (the backward's own access shapes without
+    // any arithmetic need the kernel's whole time with them) and profiles/r04_store_shapes.txt (the kernel without its stores: 0.32
+    // instead of 0.46 ms on the same box).  So the bf16 results of a stage go through LDS and leave as FULL 128-byte token rows, 16
+    // bytes per lane: staging area [tensor gr | gk | gw | gv][32 tokens of the stage][GRS = 144-byte rows] laid over the published G
+    // operand (GOP_OFF: 128 rows of 144 bytes).  Row wave w is the only reader of byte columns [32w, 32w + 32) of the operand's rows
+    // (take_gop), and its tile of a staged token row is exactly those 32 bytes: once it has taken block 0's operand -- the last of the
+    // stage -- it may write its tiles of gr, gk, gw (staging rows 0..95) without asking anybody.  The column waves' gv (rows 96..127)
+    // waits for all four row waves to have taken theirs (TAG_GE).  When the four waves of a role have staged their tiles (TAG_GD / TAG_GF)
+    // each stores token rows 8w .. 8w+7 of the stage: one 16-byte-per-lane instruction per tensor.  The stage barrier that follows
+    // orders these reads before the next stage's operand.  (SPLIT: no published operand, the region is free; same protocol without TAG_GE.)
+    const int x_ = lane & 15, g_ = lane >> 4;
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    typedef volatile v2u_t __attribute__((address_space(3))) lds_vv2u;
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    typedef volatile v4u_t __attribute__((address_space(3))) lds_vv4u;
+    constexpr int SLOT_OF[4] = {0, 1, 3, 2};                        // tensor index (gr, gk, gv, gw) -> staging slot
+    auto stage_put = [&](int which, int blk, uint2 v) {             // this lane: token x_ of the block, channels 16 wv + 4 g_ .. + 3
+        *(lds_vv2u*)(smem + GOP_OFF + (SLOT_OF[which] * STG + blk * BLK + x_) * GRS + 32 * wv + 8 * g_) = v2u_t{v.x, v.y};
+    };
+    auto staged = [&](int which) { return !(GEN == 1 && a.g_f32[which]); };
+    auto stage_flush = [&](int which, const rsrc_t& rs, int stg, unsigned bit) {   // token rows 8 wv .. 8 wv + 7, 128 bytes each
+        if (!staged(which)) return;
+        const int row = 8 * wv + (lane >> 3);
+        const v4u_t d = *(lds_vv4u*)(smem + GOP_OFF + (SLOT_OF[which] * STG + row) * GRS + 16 * (lane & 7));
+        const unsigned idx = (unsigned)(tokmap(stg * STG + row, bit) * a.C + 8 * (lane & 7));
+        WKV6_T5(2, tp0);
+        buf_store16(rs, idx * 2u, make_uint4(d.x, d.y, d.z, d.w));
+        WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
+    };
+    // the result of one block: fp32 side buffer (first half of wkv6_bi: 64-byte pieces, 16 bytes per lane as they are) or the packed
+    // bf16 quad for the staging area
+    auto emit = [&](int which, int stg, int blk, unsigned bit, float (&o)[4], const float (&old)[4]) -> uint2 {
         if constexpr (GEN == 1) {
-            if (a.g_f32[which]) { buf_store16f(rs_side[which], idx * 4u, o); return; }
+            if (a.g_f32[which]) {
+                const unsigned idx = (unsigned)(tokmap(stg * STG + blk * BLK + x_, bit) * a.C + 16 * wv + 4 * g_);
+                buf_store16f(rs_side[which], idx * 4u, o);
+                return make_uint2(0u, 0u);
+            }
         }
         if constexpr (GEN == 2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] += old[q];
         }
-        buf_store8(rs, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
+        return make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
     };
 
-#ifdef WKV6_STAMP
-    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
-#endif
 #ifdef WKV6_DEBUGBUF
     unsigned long long clk0 = 0, rtc0 = 0, clk1 = 0, rtc1 = 0;
     WKV6_CLK(clk0, rtc0);
@@ -420,11 +471,9 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // (explicit LDS address space: a volatile access through a generic pointer becomes a FLAT instruction whose wait drains the whole
     // vector-memory queue)
     typedef volatile int __attribute__((address_space(3))) lds_vint;
-    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-    typedef volatile v4u_t __attribute__((address_space(3))) lds_vv4u;
-    // tag slot idx: the padding (bytes 128..159) of image rows 0, 1, 2 of the first array, eight per row
+    // tag slot idx: the padding (bytes 128..159) of image rows 0 .. 3 of the first array, eight per row
     auto xflag_at = [&](int idx) { return (lds_vint*)(smem + (idx >> 3) * RSB + XFLAG_OFF + (idx & 7) * 4); };
-    if (tid < N_TAGS + 4) *xflag_at(tid) = 0;                     // (ordered before any use by the barrier that opens the first stage)
+    if (tid < N_TAGS) *xflag_at(tid) = 0;                     // (ordered before any use by the barrier that opens the first stage)
     // Hand-over protocol.  Tile stores, tag stores, tag polls and tile loads are all volatile accesses: the compiler keeps their program
     // order among themselves (and the LDS executes one wave's operations in order) without a full memory barrier, which would stop it
     // from keeping the stage's many independent operand reads in flight around them.  The non-volatile operand reads that must stay
@@ -447,18 +496,20 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #define WKV6_SPIN_GUARD(idx, tag, seen) do { } while (0)
 #endif
     // readers poll two / four adjacent tags with one LDS round trip (a poll costs an LDS latency plus a drain of the wave's LDS queue)
-    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
     auto await2 = [&](int idx, int tag) {
         [[maybe_unused]] unsigned spins = 0;
+        WKV6_T5(1, tp0);
         for (;;) {
             const v2u_t f = *(volatile v2u_t __attribute__((address_space(3)))*)xflag_at(idx);
             if (__builtin_amdgcn_readfirstlane((int)((f.x ^ (unsigned)tag) | (f.y ^ (unsigned)tag))) == 0) break;
             WKV6_SPIN_GUARD(idx, tag, f.x);
             __builtin_amdgcn_s_sleep(1);
         }
+        WKV6_T5(1, tp1); WKV6_ACC5(1, tp1, tp0); WKV6_ACCP(idx, tp1, tp0);
     };
     auto await4 = [&](int idx, int tag) {
         [[maybe_unused]] unsigned spins = 0;
+        WKV6_T5(1, tp0);
         for (;;) {
             const v4u_t f = *(lds_vv4u*)xflag_at(idx);
             const unsigned t = (unsigned)tag;
@@ -466,6 +517,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             WKV6_SPIN_GUARD(idx, tag, f.x);
             __builtin_amdgcn_s_sleep(1);
         }
+        WKV6_T5(1, tp1); WKV6_ACC5(1, tp1, tp0); WKV6_ACCP(idx, tp1, tp0);
     };
     auto tile_store = [&](int off, uint2 hi, uint2 lo) {
         *(lds_vv4u*)(smem + off + lane * 16) = v4u_t{hi.x, hi.y, lo.x, lo.y};
@@ -569,7 +621,20 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 for (int q = 0; q < 4; ++q) Sout[jt][q] = fmaf(e16, Sin[jt][q], e16m8 * o[q]);
             }
         };
+        // (as for the column waves' G below: whatever was loaded for the loop is waited for in front of it)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(ue[q]), "+v"(Rc[q]));
         if (ngrp > 0) request_ckpt(ngrp - 1);
+        // The vector-memory counter counts loads and stores alike, in order.  Inside the loop the checkpoint request of a stage is
+        // followed by its three gradient stores, so the wait for the first checkpoint register may leave six requests in flight; hipcc
+        // sizes the one s_waitcnt at the loop head for the worse of its two entries, and on first entry only the other three checkpoint
+        // loads follow -- vmcnt(3 .. 0) would then wait, every stage, for the stores of the stage before to be acknowledged.  Three
+        // stores that the bounds check drops give the first entry the same queue.
+        if constexpr (GEN != 1) {
+            const rsrc_t rs_none = make_rsrc(static_cast<bf16_t*>(nullptr), 0u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) buf_store16(rs_none, 16u * i, make_uint4(0u, 0u, 0u, 0u));   // (distinct: identical ones are merged)
+        }
 
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
@@ -672,6 +737,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
             f4v ackp[SBLK];
             float at[SBLK][4], vgs[SBLK];
+            uint2 held_gr[SBLK];                                  // gr waits for this wave's stripe of the staging area (free behind take_gop(0))
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const rb = rpart(grp, blk);
@@ -733,17 +799,24 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
                         at[blk][q] = rv[q] * dq;
                     }
-                    const int p = grp * STG + blk * BLK + x;
-                    emit(0, rs_gr, p, REV_R, ch, o_gr, old_gr);
+                    held_gr[blk] = emit(0, grp, blk, REV_R, o_gr, old_gr);
                 }
             }
             WKV6_T(ts3);
             // the next stage's checkpoint: the state registers of this stage are dead from here on
+            WKV6_T5(2, tp0);
             if (grp > 0) request_ckpt(grp - 1);
+            WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
             if constexpr (!SPLIT) {
                 await4(TAG_GC, grp + 1);
                 gvb[0] = take_gop(0);
+                // The last reads of this wave's stripe of the operand are in the LDS queue, which serves a wave's requests in order
+                // (and a store is never moved above a load it may alias): from here on the stripe is this wave's part of the staging
+                // area, and the tag tells the column waves so for their rows of it.
+                publish(TAG_GE + wv, grp + 1);
             }
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) stage_put(0, blk, held_gr[blk]);
             // ---- chain: only the work that needs G
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
@@ -816,9 +889,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         o_gw[q] = (Rc[q] + (sfx[q] - dl[q]) - bt[q]) * lwv[q];
                         Rc[q] += total;
                     }
-                    const int p = grp * STG + blk * BLK + x;
-                    emit(1, rs_gk, p, REV_K, ch, o_gk, old_gk);
-                    emit(3, rs_gw, p, REV_W, ch, o_gw, old_gw);
+                    stage_put(1, blk, emit(1, grp, blk, REV_K, o_gk, old_gk));
+                    stage_put(3, blk, emit(3, grp, blk, REV_W, o_gw, old_gw));
                 }
                 // ---- (SPLIT) G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
                 if constexpr (SPLIT) {
@@ -828,6 +900,12 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * Oi[jt][q]);
                 }
             }
+            // the stage's gr, gk, gw leave as full token rows
+            publish(TAG_GD + wv, grp + 1);
+            await4(TAG_GD, grp + 1);
+            stage_flush(0, rs_gr, grp, REV_R);
+            stage_flush(1, rs_gk, grp, REV_K);
+            stage_flush(3, rs_gw, grp, REV_W);
             WKV6_T(ts4);
             __syncthreads();
             WKV6_T(ts5);
@@ -854,6 +932,11 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 io4<float>::load(a.g_in + ((long)b * a.H + h) * HEAD * HEAD + (long)(16 * wv + x) * HEAD + tile_ch(t) + 8 * g, t4);
             GJ[t] = f4v{t4[0], t4[1], t4[2], t4[3]};
         }
+        // The wait for these loads belongs HERE.  A loop-carried register whose first value is a load still in flight makes hipcc put
+        // its s_waitcnt at the first use INSIDE the stage loop, sized for the loop's first entry -- vmcnt(0) -- where it then waits,
+        // every stage, for the requests that stage has just issued (measured: the operand of block 1 published 1100 cycles late).
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(GJ[t]));
         // this wave's share of the PREPARATION: v (K part, stage s-2) and gy (R part, stage s-1) of tokens 4wv .. 4wv+3 of both blocks go from
         // global memory into the images, with the two half sums of vg_a = gy_a . v_a (the v of a stage is kept in registers for the one
         // iteration until its gy arrives).  lane = (token tl, channels 4cl .. 4cl+3); requested at the head of a stage, written at its end.
@@ -908,8 +991,14 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             WKV6_T(ts0);
+            WKV6_T5(2, tp0);
             if (!SPLIT && grp > 0) load_gy(grp - 1);
             if (!SPLIT && grp > 1) load_v(grp - 2);
+            WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
+#if defined(WKV6_STAMP) && WKV6_STAMP5 == 3
+            unsigned long long tq0, tq1;
+            WKV6_T(tq0); poll_acc[0] += tq0 - ts0;                 // diagnostic: stage start -> loads issued
+#endif
             // ---- the stage's G recurrence, first thing: per block (1, then 0) scale by E16m8, split, publish the operand for the row
             // waves (stored [j][i]: this lane's 16 bytes are key rows 32s + 8g .. +7 of value column 16wv + x), keep the fragments for
             // this wave's own chain, and move G to the entry of the block
@@ -942,6 +1031,9 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     *(lds_vv4u*)(dst + HEAD * GRS) = __builtin_bit_cast(v4u_t, gl[blk][s]);
                 }
                 publish((blk ? TAG_GA : TAG_GC) + wv, grp + 1);
+#if defined(WKV6_STAMP) && WKV6_STAMP5 == 3
+                WKV6_T(tq1); poll_acc[blk ? 2 : 4] += tq1 - tq0;   // -> GA published / -> GC published (includes the GB poll)
+#endif
                 const s4v gyT = tr_read(rb + R_GY * ARR + troff + 32 * wv);           // gy[4g+e][16wv + x]
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {              // (Rhat^T gy) tile [row i_local][col j_local = x];  G <- E16 G + E8 (Rhat^T gy)
@@ -1016,6 +1108,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             }
             WKV6_T(ts1);
             // ---- chain: only the work that needs G
+            uint2 held_gv[SBLK];
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const kb = kpart(grp, blk);
@@ -1041,9 +1134,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 }
                 acc += accp[blk];
                 {
-                    const int p = grp * STG + blk * BLK + x;
                     float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-                    emit(2, rs_gv, p, REV_V, 16 * wv + 4 * g, o, old_gv);
+                    held_gv[blk] = emit(2, grp, blk, REV_V, o, old_gv);
                 }
                 // ---- (SPLIT) G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
                 if constexpr (SPLIT) {
@@ -1059,8 +1151,16 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     }
                 }
             }
+            // gv leaves as full token rows through the staging area (rows 96..127 of the operand region: free once every row wave
+            // has taken block 0's operand); the copies for the stages behind run between the hand-over and its poll
+            if constexpr (!SPLIT) await4(TAG_GE, grp + 1);
+#pragma unroll
+            for (int blk = 0; blk < SBLK; ++blk) stage_put(2, blk, held_gv[blk]);
+            publish(TAG_GF + wv, grp + 1);
             if (!SPLIT && grp > 0) copy_gy(grp - 1);           // (uses cvp = v of stage s-1, before copy_v replaces it)
             if (!SPLIT && grp > 1) copy_v(grp - 2);
+            await4(TAG_GF, grp + 1);
+            stage_flush(2, rs_gv, grp, REV_V);
             WKV6_T(ts2);
             __syncthreads();
             WKV6_T(ts3);
@@ -1082,6 +1182,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)bh * 16 + wid) * 8;
 #ifdef WKV6_STAMP
         for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
+        if (wid == 0 || wid == 4) for (int i = 0; i < 8; ++i) d[(12 + (wid >> 2) - wid) * 8 + i] = poll_acc[i];   // records 12 / 13
 #endif
         d[6] = clk1 - clk0;
         d[7] = rtc1 - rtc0;
@@ -1100,7 +1201,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 }
 
 template <bool W_RAW, int GEN, bool SPLIT>
-__global__ __launch_bounds__(768) void chunk_bwd12k_kernel(const ScanArgs a)
+__global__ __launch_bounds__(SPLIT ? 512 : 768) void chunk_bwd12k_kernel(const ScanArgs a)
 {
     chunk_bwd12k_body<W_RAW, GEN, SPLIT>(a, blockIdx.x);
 }

@@ -47,6 +47,11 @@ __device__ __forceinline__ void buf_store16f(rsrc_t r, unsigned off, const float
     __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
                                            r, (int)off, 0, 0);
 }
+__device__ __forceinline__ void buf_store16(rsrc_t r, unsigned off, uint4 v)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{v.x, v.y, v.z, v.w}, r, (int)off, 0, 0);
+}
 __device__ __forceinline__ void buf_store8(rsrc_t r, unsigned off, uint2 v)
 {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));

@@ -84,4 +84,7 @@ if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wav
     print("  col waves 4-7  = [pre-phase, chain, barrier]")
     print("  producers 8-11 = [load wait, prep, load issue, barrier]")
     for wv in range(12):
-        print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / ns):8.0f}" for k in range(5)))
+        print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / ns):8.0f}" for k in range(6)))
+    print("  cycles inside tag polls per stage, by tag group [DA SC GA GB GC GD GE GF]: row wave 0 / column wave 4")
+    for rec in (12, 13):
+        print(f"  rec  {rec:2d}: " + "  ".join(f"{(d[rec, k].item() / ns):8.0f}" for k in range(8)))
