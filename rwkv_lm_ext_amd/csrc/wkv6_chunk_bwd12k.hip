@@ -29,7 +29,7 @@
 // One 768-thread workgroup (12 wave64) per (batch, head), one barrier per stage, three roles with one wave of each per SIMD (<= 168 VGPRs):
 //   * "row" waves 0..3 own key rows [16w,16w+16): forward states with lane = key row; they produce gr, gk, gw, gu;
 //   * "column" waves 4..7 own value columns [16w,16w+16) and the adjoint state G (lane = value column); they produce gv, gs, run the
-//     stage's G recurrence first thing and publish the operand (E16m8 (.) G) hi | lo through LDS for the row waves' gk (GOP_OFF below),
+//     stage's G recurrence early and publish the operand (E16m8 (.) G) hi | lo through LDS for the row waves' gk (GOP_OFF below),
 //     and they copy v (of stage s-2, K part) and gy (of stage s-1, R part) from global memory into the images;
 //   * four producer waves (wave = block x channel half, lane = 4 channels x 2 tokens) prepare the R part of stage s-1 and the K part of
 //     stage s-2 while stage s is consumed, having requested the inputs of the stages behind those before they start;
@@ -74,12 +74,14 @@ constexpr int XS_OFF = XT_OFF + 4 * 1024;                              // uint4 
 constexpr int XFLAG_OFF = 128;                                         // int [6] in the padding of row 0 of the first array of buffer 0
 // G once per workgroup: the column waves own the adjoint state and publish the operand the row waves need, (E16m8 (.) G) split into
 // bf16 hi | lo, stored [value column j][key row i] with 144-byte rows, twice per stage (for block 1, then for block 0: one buffer, tags
-// GA "block 1's version is there" / GB "taken" / GC "block 0's version is there"); the row waves take it with transposing reads
-// instead of carrying, updating, scaling and splitting a second copy of G by rows.  The column waves run the stage's G recurrence
-// first thing, the row waves need its products last: nobody waits.
+// GA "block 1's version is there" / GB "taken" / GC "block 0's version is there" / GD "taken"); the row waves take it with transposing
+// reads instead of carrying, updating, scaling and splitting a second copy of G by rows.  A tag needs ~1000 cycles from one wave's
+// LDS queue into another wave's poll while the LDS is busy (profiles/r04_handover_timeline.txt), so the chain GA -> GB -> GC is kept
+// off the row waves' path: block 1's version of a stage is written in the TAIL of the stage before it (behind GD; the stage barrier
+// orders it), the row waves take it first thing and release it (GB) some 1500 cycles before they need block 0's.
 constexpr int GRS = 144;                                               // bytes per row of the published operand
 constexpr int GOP_OFF = XS_OFF + 2 * 1024;                             // bf16 [2 (hi | lo)][64][GRS / 2]
-constexpr int TAG_DA = 0, TAG_SC = 4, TAG_GA = 8, TAG_GB = 12, TAG_GC = 16, TAG_GD = 20, TAG_GE = 24, TAG_GF = 28, N_TAGS = 32;   // tag slots (see xflag)
+constexpr int TAG_DA = 0, TAG_SC = 4, TAG_GA = 8, TAG_GB = 12, TAG_GC = 16, TAG_GD = 20, N_TAGS = 24;   // tag slots (see xflag)
 constexpr int BWD12K_LDS = GOP_OFF + 2 * HEAD * GRS;
 static_assert(BWD12K_LDS <= 160 * 1024, "LDS budget");
 
@@ -176,44 +178,43 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #ifndef WKV6_STAMP5
 #define WKV6_STAMP5 1
 #endif
-#define WKV6_T5(kind, var) do { if (WKV6_STAMP5 == (kind) || ((kind) == 1 && WKV6_STAMP5 == 3)) WKV6_T(var); } while (0)
+#define WKV6_T5(kind, var) do { if (WKV6_STAMP5 == (kind)) WKV6_T(var); } while (0)
 #define WKV6_ACC5(kind, t1, t0) do { if (WKV6_STAMP5 == (kind)) stamp_acc[5] += (t1) - (t0); } while (0)
     unsigned long long poll_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // cycles inside the polls of each tag group (DA SC GA GB GC GD GE GF)
-#define WKV6_ACCP(idx, t1, t0) do { if (WKV6_STAMP5 == 1 || (WKV6_STAMP5 == 3 && ((idx) >> 2) != 0 && ((idx) >> 2) != 2 && ((idx) >> 2) != 4)) poll_acc[(idx) >> 2] += (t1) - (t0); } while (0)
+#define WKV6_ACCP(idx, t1, t0) do { if (WKV6_STAMP5 == 1) poll_acc[(idx) >> 2] += (t1) - (t0); } while (0)
+// -DWKV6_STAMP5=3: times of the hand-over events since the start of the stage instead (records 12 / 13, see tools/time_ops.py)
+#define WKV6_EV(k) do { if (WKV6_STAMP5 == 3) { unsigned long long te_; WKV6_T(te_); poll_acc[k] += te_ - ts0; } } while (0)
 #else
 #define WKV6_ACCP(idx, t1, t0) do { } while (0)
+#define WKV6_EV(k) do { } while (0)
 #define WKV6_T5(kind, var) do { } while (0)
 #define WKV6_ACC5(kind, t1, t0) do { } while (0)
 #endif
-    // Gradient stores.  A wave's result tile is 16 tokens x 16 channels -- 32 bytes per token row of the [B, T, C] tensors -- and the
-    // memory pipeline takes stores of such pieces badly: tools/microbench/head_slices.hip (the backward's own access shapes without
-    // any arithmetic need the kernel's whole time with them) and profiles/r04_store_shapes.txt (the kernel without its stores: 0.32
-    // instead of 0.46 ms on the same box).  So the bf16 results of a stage go through LDS and leave as FULL 128-byte token rows, 16
-    // bytes per lane: staging area [tensor gr | gk | gw | gv][32 tokens of the stage][GRS = 144-byte rows] laid over the published G
-    // operand (GOP_OFF: 128 rows of 144 bytes).  Row wave w is the only reader of byte columns [32w, 32w + 32) of the operand's rows
-    // (take_gop), and its tile of a staged token row is exactly those 32 bytes: once it has taken block 0's operand -- the last of the
-    // stage -- it may write its tiles of gr, gk, gw (staging rows 0..95) without asking anybody.  The column waves' gv (rows 96..127)
-    // waits for all four row waves to have taken theirs (TAG_GE).  When the four waves of a role have staged their tiles (TAG_GD / TAG_GF)
-    // each stores token rows 8w .. 8w+7 of the stage: one 16-byte-per-lane instruction per tensor.  The stage barrier that follows
-    // orders these reads before the next stage's operand.  (SPLIT: no published operand, the region is free; same protocol without TAG_GE.)
+    // Gradient stores.  A wave's result tile is 16 tokens x 16 channels: 32 bytes per token row of the [B, T, C] tensors.  Block 1's packed
+    // bf16 result waits for block 0's; one v_permlane16_swap per dword then gives the even lane rows block 1 (own four channels + the odd
+    // partner row's four) and the odd rows block 0: ONE 16-byte-per-lane instruction stores both blocks of a stage.  (Measured, same box,
+    // profiles/r04_store_modes.txt: 8-byte stores per block 0.4246 ms, this 0.4036-0.4064, full 128-byte rows through an LDS staging
+    // area 0.4135-0.4185 -- its two extra hand-overs cost more than the wider rows gain; tools/microbench/head_slices.hip has the shapes
+    // without arithmetic.)
     const int x_ = lane & 15, g_ = lane >> 4;
     typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-    typedef volatile v2u_t __attribute__((address_space(3))) lds_vv2u;
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     typedef volatile v4u_t __attribute__((address_space(3))) lds_vv4u;
-    constexpr int SLOT_OF[4] = {0, 1, 3, 2};                        // tensor index (gr, gk, gv, gw) -> staging slot
-    auto stage_put = [&](int which, int blk, uint2 v) {             // this lane: token x_ of the block, channels 16 wv + 4 g_ .. + 3
-        *(lds_vv2u*)(smem + GOP_OFF + (SLOT_OF[which] * STG + blk * BLK + x_) * GRS + 32 * wv + 8 * g_) = v2u_t{v.x, v.y};
-    };
-    auto staged = [&](int which) { return !(GEN == 1 && a.g_f32[which]); };
-    auto stage_flush = [&](int which, const rsrc_t& rs, int stg, unsigned bit) {   // token rows 8 wv .. 8 wv + 7, 128 bytes each
-        if (!staged(which)) return;
-        const int row = 8 * wv + (lane >> 3);
-        const v4u_t d = *(lds_vv4u*)(smem + GOP_OFF + (SLOT_OF[which] * STG + row) * GRS + 16 * (lane & 7));
-        const unsigned idx = (unsigned)(tokmap(stg * STG + row, bit) * a.C + 8 * (lane & 7));
-        WKV6_T5(2, tp0);
-        buf_store16(rs, idx * 2u, make_uint4(d.x, d.y, d.z, d.w));
-        WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
+#ifndef WKV6_STORE_MODE
+#define WKV6_STORE_MODE 1        // experiment switch: 0 = 8-byte stores per block
+#endif
+    [[maybe_unused]] uint2 held_st[4] = {};
+    auto put = [&](int which, const rsrc_t& rs, int stg, int blk, unsigned bit, uint2 v) {   // this lane: token x_ of the block, channels 16 wv + 4 g_ .. + 3
+        if (GEN == 1 && a.g_f32[which]) return;                    // (went to the fp32 side buffer in emit)
+#if WKV6_STORE_MODE == 0
+        buf_store8(rs, (unsigned)(tokmap(stg * STG + blk * BLK + x_, bit) * a.C + 16 * wv + 4 * g_) * 2u, v);
+#else
+        if (blk == SBLK - 1) { held_st[which] = v; return; }      // (the stage's blocks are walked 1, 0)
+        const auto sx = __builtin_amdgcn_permlane16_swap(held_st[which].x, v.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(held_st[which].y, v.y, false, false);
+        const int p = stg * STG + ((g_ & 1) ? 0 : BLK) + x_;         // even lane rows: block 1's token, odd rows: block 0's
+        buf_store16(rs, (unsigned)(tokmap(p, bit) * a.C + 16 * wv + 8 * (g_ >> 1)) * 2u, make_uint4(sx[0], sy[0], sx[1], sy[1]));
+#endif
     };
     // the result of one block: fp32 side buffer (first half of wkv6_bi: 64-byte pieces, 16 bytes per lane as they are) or the packed
     // bf16 quad for the staging area
@@ -471,7 +472,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // (explicit LDS address space: a volatile access through a generic pointer becomes a FLAT instruction whose wait drains the whole
     // vector-memory queue)
     typedef volatile int __attribute__((address_space(3))) lds_vint;
-    // tag slot idx: the padding (bytes 128..159) of image rows 0 .. 3 of the first array, eight per row
+    // tag slot idx: the padding (bytes 128..159) of image rows 0, 1, 2 of the first array, eight per row
     auto xflag_at = [&](int idx) { return (lds_vint*)(smem + (idx >> 3) * RSB + XFLAG_OFF + (idx & 7) * 4); };
     if (tid < N_TAGS) *xflag_at(tid) = 0;                     // (ordered before any use by the barrier that opens the first stage)
     // Hand-over protocol.  Tile stores, tag stores, tag polls and tile loads are all volatile accesses: the compiler keeps their program
@@ -518,6 +519,15 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             __builtin_amdgcn_s_sleep(1);
         }
         WKV6_T5(1, tp1); WKV6_ACC5(1, tp1, tp0); WKV6_ACCP(idx, tp1, tp0);
+    };
+    // A poll whose tag is already there still costs an LDS round trip with the wave's LDS queue drained.  Where the schedule allows, the
+    // tag read is issued ahead (peek4) with independent work behind it and only examined later (settle4): satisfied -- the usual case --
+    // it costs a compare; otherwise the ordinary poll takes over.  Readers of the handed-over data are volatile accesses or get
+    // their address through an asm volatile behind settle4, as after await4: the LDS serves a wave's requests in order.
+    auto peek4 = [&](int idx) -> v4u_t { return *(lds_vv4u*)xflag_at(idx); };
+    auto settle4 = [&](int idx, int tag, const v4u_t f) {
+        const unsigned t = (unsigned)tag;
+        if (__builtin_amdgcn_readfirstlane((int)((f.x ^ t) | (f.y ^ t) | (f.z ^ t) | (f.w ^ t))) != 0) await4(idx, tag);
     };
     auto tile_store = [&](int off, uint2 hi, uint2 lo) {
         *(lds_vv4u*)(smem + off + lane * 16) = v4u_t{hi.x, hi.y, lo.x, lo.y};
@@ -633,13 +643,42 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         if constexpr (GEN != 1) {
             const rsrc_t rs_none = make_rsrc(static_cast<bf16_t*>(nullptr), 0u);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) buf_store16(rs_none, 16u * i, make_uint4(0u, 0u, 0u, 0u));   // (distinct: identical ones are merged)
+            for (int i = 0; i < (WKV6_STORE_MODE == 0 ? 6 : 3); ++i) buf_store16(rs_none, 16u * i, make_uint4(0u, 0u, 0u, 0u));   // (distinct: identical ones are merged)
         }
 
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             WKV6_T(ts0);
-            // first of all, so that it is there long before the others ask for it:
+            // ---- G-dependent part of gk, decoupled from the epilogues: sum_j (E16m8 G)[i][j] v_b[j] per block from the operand
+            //      the column waves publish; block 1's version is taken (and released: GB) here, block 0's behind the pre-phase
+            f4v gvb[SBLK];
+            auto take_gop = [&](int blk) {
+                int base_ = GOP_OFF + (8 * g + (x >> 2)) * GRS + (16 * wv + 4 * (x & 3)) * 2;
+                asm volatile("" : "+v"(base_));                    // keeps the reads behind the tag polls that precede the call
+                typedef short s8v __attribute__((ext_vector_type(8)));
+                const char* const kb = kpart(grp, blk);
+                f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {   // lane (x, g): key row 16wv + x, value columns 32s + 8g .. +7 (stored [j][i]: transposing reads)
+                    const char* const ph = smem + base_ + 32 * s * GRS;
+                    const s8v h8 = __builtin_shufflevector(tr_read(ph), tr_read(ph + 4 * GRS), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s8v l8 = __builtin_shufflevector(tr_read(ph + HEAD * GRS), tr_read(ph + HEAD * GRS + 4 * GRS), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const b8v vr = ld_b8(kb + K_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
+                    acc = mfma32(__builtin_bit_cast(b8v, h8), vr, acc);
+                    acc = mfma32(__builtin_bit_cast(b8v, l8), vr, acc);
+                }
+                return acc;
+            };
+            if constexpr (!SPLIT) {   // first of all: block 1's operand is there (published before the stage barrier; the first stage polls) --
+                                      // taking it now releases it ~1500 cycles earlier for the column waves to lay block 0's over it
+                if (grp == ngrp - 1) await4(TAG_GA, grp + 1);
+                WKV6_EV(0);
+                gvb[1] = take_gop(1);
+                asm volatile("" :: "v"(gvb[1]));               // (the operand reads have returned)
+                publish(TAG_GB + wv, grp + 1);
+                WKV6_EV(1);
+            }
+            // then, so that it is there long before the others ask for it:
             if (wv >= 2) {   // this wave's dA tiles of the stage: block wv - 2, both orientations (tile 2 blk: dA[a][b], lane col b; 2 blk + 1:
                              // dA^T[b][a], lane col a) from one pair of operand reads.  Row waves 0 and 1 make the score tiles instead.
                 const int tb = wv - 2;
@@ -704,35 +743,11 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 advance(kpart(grp - 1, 1), ST[0], ST[0]);
             }
             // ---- rebuild the entry state of block 1
+            [[maybe_unused]] v4u_t pk_gc = {};
 #pragma unroll
             for (int blk = 0; blk < SBLK - 1; ++blk) advance(kpart(grp, blk), ST[blk], ST[blk + 1]);
+            const v4u_t pk_da = peek4(TAG_DA);                    // (examined where the pre-phase starts)
             WKV6_T(ts2);
-            // ---- G-dependent part of gk, decoupled from the epilogues: sum_j (E16m8 G)[i][j] v_b[j] per block from the operand
-            //      the column waves publish; block 1's version is taken (and released: GB) here, block 0's behind the pre-phase
-            f4v gvb[SBLK];
-            auto take_gop = [&](int blk) {
-                int base_ = GOP_OFF + (8 * g + (x >> 2)) * GRS + (16 * wv + 4 * (x & 3)) * 2;
-                asm volatile("" : "+v"(base_));                    // keeps the reads behind the tag polls that precede the call
-                typedef short s8v __attribute__((ext_vector_type(8)));
-                const char* const kb = kpart(grp, blk);
-                f4v acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {   // lane (x, g): key row 16wv + x, value columns 32s + 8g .. +7 (stored [j][i]: transposing reads)
-                    const char* const ph = smem + base_ + 32 * s * GRS;
-                    const s8v h8 = __builtin_shufflevector(tr_read(ph), tr_read(ph + 4 * GRS), 0, 1, 2, 3, 4, 5, 6, 7);
-                    const s8v l8 = __builtin_shufflevector(tr_read(ph + HEAD * GRS), tr_read(ph + HEAD * GRS + 4 * GRS), 0, 1, 2, 3, 4, 5, 6, 7);
-                    const b8v vr = ld_b8(kb + K_V * ARR + x * RSB + (32 * s + 8 * g) * 2);
-                    acc = mfma32(__builtin_bit_cast(b8v, h8), vr, acc);
-                    acc = mfma32(__builtin_bit_cast(b8v, l8), vr, acc);
-                }
-                return acc;
-            };
-            if constexpr (!SPLIT) {
-                await4(TAG_GA, grp + 1);
-                gvb[1] = take_gop(1);
-                asm volatile("" :: "v"(gvb[1]));               // (the operand reads have returned)
-                publish(TAG_GB + wv, grp + 1);
-            }
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
             f4v ackp[SBLK];
@@ -750,7 +765,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 // vg_x = dA[x][x] = gy_x . v_x: the two half sums
                 const float vg = *reinterpret_cast<const float*>(rb + ROFF_VG + x * 4) + *reinterpret_cast<const float*>(rb + ROFF_VG + 64 + x * 4);
                 vgs[blk] = vg;
-                if (blk == SBLK - 1) await4(TAG_DA, grp + 1);     // all four dA tiles of the stage with one poll
+                if (blk == SBLK - 1) settle4(TAG_DA, grp + 1, pk_da);   // all four dA tiles of the stage with one poll
+                if constexpr (!SPLIT) { if (blk == 0) pk_gc = peek4(TAG_GC); }   // (examined behind the pre-phase)
                 const uint4 fab = tile_load(XT_OFF + (2 * blk) * 1024), fba = tile_load(XT_OFF + (2 * blk + 1) * 1024);
                 const s4v dab_hi = __builtin_bit_cast(s4v, make_uint2(fab.x, fab.y)), dab_lo = __builtin_bit_cast(s4v, make_uint2(fab.z, fab.w));
                 const s4v dba_hi = __builtin_bit_cast(s4v, make_uint2(fba.x, fba.y)), dba_lo = __builtin_bit_cast(s4v, make_uint2(fba.z, fba.w));
@@ -808,15 +824,16 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             if (grp > 0) request_ckpt(grp - 1);
             WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
             if constexpr (!SPLIT) {
-                await4(TAG_GC, grp + 1);
+                WKV6_EV(2);
+                settle4(TAG_GC, grp + 1, pk_gc);
+                WKV6_EV(3);
                 gvb[0] = take_gop(0);
-                // The last reads of this wave's stripe of the operand are in the LDS queue, which serves a wave's requests in order
-                // (and a store is never moved above a load it may alias): from here on the stripe is this wave's part of the staging
-                // area, and the tag tells the column waves so for their rows of it.
-                publish(TAG_GE + wv, grp + 1);
+                // Released for the column waves (they lay the NEXT stage's first operand over it): this wave's reads are in the LDS
+                // queue, which serves a wave's requests in order, and a store is never moved above a load it may alias.
+                publish(TAG_GD + wv, grp + 1);
             }
 #pragma unroll
-            for (int blk = 0; blk < SBLK; ++blk) stage_put(0, blk, held_gr[blk]);
+            for (int blk = SBLK - 1; blk >= 0; --blk) put(0, rs_gr, grp, blk, REV_R, held_gr[blk]);
             // ---- chain: only the work that needs G
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
@@ -889,8 +906,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         o_gw[q] = (Rc[q] + (sfx[q] - dl[q]) - bt[q]) * lwv[q];
                         Rc[q] += total;
                     }
-                    stage_put(1, blk, emit(1, grp, blk, REV_K, o_gk, old_gk));
-                    stage_put(3, blk, emit(3, grp, blk, REV_W, o_gw, old_gw));
+                    put(1, rs_gk, grp, blk, REV_K, emit(1, grp, blk, REV_K, o_gk, old_gk));
+                    put(3, rs_gw, grp, blk, REV_W, emit(3, grp, blk, REV_W, o_gw, old_gw));
                 }
                 // ---- (SPLIT) G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
                 if constexpr (SPLIT) {
@@ -900,12 +917,6 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         for (int q = 0; q < 4; ++q) GI[jt][q] = fmaf(e16x, GI[jt][q], e8x * Oi[jt][q]);
                 }
             }
-            // the stage's gr, gk, gw leave as full token rows
-            publish(TAG_GD + wv, grp + 1);
-            await4(TAG_GD, grp + 1);
-            stage_flush(0, rs_gr, grp, REV_R);
-            stage_flush(1, rs_gk, grp, REV_K);
-            stage_flush(3, rs_gw, grp, REV_W);
             WKV6_T(ts4);
             __syncthreads();
             WKV6_T(ts5);
@@ -978,6 +989,28 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 if ((cl & 7) == 0) *reinterpret_cast<float*>(rb + ROFF_VG + ((cl >> 3) * 16 + tok) * 4) = vg;
             }
         };
+        // (E16m8 of the block whose K part is kb) (.) G, split into the bf16 hi | lo fragments of the two k-steps
+        auto scale_split = [&](const char* kb, b8v (&h)[2], b8v (&l)[2]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float t0[4], t1[4];
+                const float4 m0 = *reinterpret_cast<const float4*>(kb + KOFF_E16M8 + (32 * s + 8 * g) * 4);
+                const float4 m1 = *reinterpret_cast<const float4*>(kb + KOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
+                t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
+                t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
+                t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
+                split8(t0, t1, h[s], l[s]);
+            }
+        };
+        auto gop_write = [&](const b8v (&h)[2], const b8v (&l)[2]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                char* const dst = smem + GOP_OFF + (16 * wv + x) * GRS + (32 * s + 8 * g) * 2;
+                *(lds_vv4u*)dst = __builtin_bit_cast(v4u_t, h[s]);
+                *(lds_vv4u*)(dst + HEAD * GRS) = __builtin_bit_cast(v4u_t, l[s]);
+            }
+        };
+        [[maybe_unused]] b8v nh[2] = {}, nl[2] = {};                // block 1's operand of the NEXT stage, across the barrier
         if (!SPLIT && ngrp > 0) {                                  // (SPLIT: the producers of this workgroup move v and gy)
             load_v(ngrp - 1);
             load_gy(ngrp - 1);
@@ -989,19 +1022,16 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             }
         }
         __syncthreads();                                          // first stage image is ready
+        if constexpr (!SPLIT) { if (ngrp > 0) scale_split(kpart(ngrp - 1, SBLK - 1), nh, nl); }
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             WKV6_T(ts0);
-            WKV6_T5(2, tp0);
-            if (!SPLIT && grp > 0) load_gy(grp - 1);
-            if (!SPLIT && grp > 1) load_v(grp - 2);
-            WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
-#if defined(WKV6_STAMP) && WKV6_STAMP5 == 3
-            unsigned long long tq0, tq1;
-            WKV6_T(tq0); poll_acc[0] += tq0 - ts0;                 // diagnostic: stage start -> loads issued
-#endif
-            // ---- the stage's G recurrence, first thing: per block (1, then 0) scale by E16m8, split, publish the operand for the row
-            // waves (stored [j][i]: this lane's 16 bytes are key rows 32s + 8g .. +7 of value column 16wv + x), keep the fragments for
-            // this wave's own chain, and move G to the entry of the block
+
+            // ---- the stage's G recurrence: per block (1, then 0) the operand (E16m8 (.) G) hi | lo for the row waves (stored [j][i]: this
+            // lane's 16 bytes are key rows 32s + 8g .. +7 of value column 16wv + x), kept as fragments for this wave's own chain, then G
+            // moves to the entry of the block.  Block 1's operand of a stage is published in the TAIL of the stage before it (below):
+            // a tag takes ~1000 cycles from one wave's LDS queue into another's poll while the LDS is busy, and the row waves' wait for
+            // block 0's operand -- which waits for their release of block 1's -- was the longest stall of the stage
+            // (profiles/r04_handover_timeline.txt).  Only the first stage publishes it here.
             s4v gyT_w[SBLK], sc_hi[SBLK], sc_lo[SBLK];
             f4v accp[SBLK];
             b8v gh[SBLK][2], gl[SBLK][2];
@@ -1011,29 +1041,27 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const rb = rpart(grp, blk);
                 const char* const kb = kpart(grp, blk);
+                if (blk == SBLK - 1) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float t0[4], t1[4];
-                    const float4 m0 = *reinterpret_cast<const float4*>(kb + KOFF_E16M8 + (32 * s + 8 * g) * 4);
-                    const float4 m1 = *reinterpret_cast<const float4*>(kb + KOFF_E16M8 + (32 * s + 8 * g + 4) * 4);
-                    t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
-                    t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
-                    t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
-                    split8(t0, t1, gh[blk][s], gl[blk][s]);
-                }
-                if (blk == 0) {
+                    for (int s = 0; s < 2; ++s) { gh[blk][s] = nh[s]; gl[blk][s] = nl[s]; }   // made (and published) in the previous stage's tail
+                    if (grp == ngrp - 1) {
+                        gop_write(gh[blk], gl[blk]);
+                        publish(TAG_GA + wv, grp + 1);
+                    }
+                    WKV6_EV(0);
+                    WKV6_T5(2, tp0);
+                    if (grp > 0) load_gy(grp - 1);                 // this wave's requests for the stages behind
+                    if (grp > 1) load_v(grp - 2);
+                    WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
+                } else {
+                    scale_split(kb, gh[blk], gl[blk]);
+                    WKV6_EV(1);
                     await4(TAG_GB, grp + 1);     // the row waves have taken block 1's version
+                    WKV6_EV(2);
+                    gop_write(gh[blk], gl[blk]);
+                    publish(TAG_GC + wv, grp + 1);
+                    WKV6_EV(3);
                 }
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    char* const dst = smem + GOP_OFF + (16 * wv + x) * GRS + (32 * s + 8 * g) * 2;
-                    *(lds_vv4u*)dst = __builtin_bit_cast(v4u_t, gh[blk][s]);
-                    *(lds_vv4u*)(dst + HEAD * GRS) = __builtin_bit_cast(v4u_t, gl[blk][s]);
-                }
-                publish((blk ? TAG_GA : TAG_GC) + wv, grp + 1);
-#if defined(WKV6_STAMP) && WKV6_STAMP5 == 3
-                WKV6_T(tq1); poll_acc[blk ? 2 : 4] += tq1 - tq0;   // -> GA published / -> GC published (includes the GB poll)
-#endif
                 const s4v gyT = tr_read(rb + R_GY * ARR + troff + 32 * wv);           // gy[4g+e][16wv + x]
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {              // (Rhat^T gy) tile [row i_local][col j_local = x];  G <- E16 G + E8 (Rhat^T gy)
@@ -1151,16 +1179,18 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     }
                 }
             }
-            // gv leaves as full token rows through the staging area (rows 96..127 of the operand region: free once every row wave
-            // has taken block 0's operand); the copies for the stages behind run between the hand-over and its poll
-            if constexpr (!SPLIT) await4(TAG_GE, grp + 1);
 #pragma unroll
-            for (int blk = 0; blk < SBLK; ++blk) stage_put(2, blk, held_gv[blk]);
-            publish(TAG_GF + wv, grp + 1);
+            for (int blk = SBLK - 1; blk >= 0; --blk) put(2, rs_gv, grp, blk, REV_V, held_gv[blk]);
+            if constexpr (!SPLIT) {
+                if (grp > 0) {   // block 1's operand of the next stage (G is at its entry since block 0's update; its K part has been in the ring for a stage)
+                    scale_split(kpart(grp - 1, SBLK - 1), nh, nl);
+                    await4(TAG_GD, grp + 1);                       // every row wave has taken block 0's operand of this stage
+                    gop_write(nh, nl);
+                    publish(TAG_GA + wv, grp);                     // (ordered before the row waves' reads by the stage barrier as well)
+                }
+            }
             if (!SPLIT && grp > 0) copy_gy(grp - 1);           // (uses cvp = v of stage s-1, before copy_v replaces it)
             if (!SPLIT && grp > 1) copy_v(grp - 2);
-            await4(TAG_GF, grp + 1);
-            stage_flush(2, rs_gv, grp, REV_V);
             WKV6_T(ts2);
             __syncthreads();
             WKV6_T(ts3);
@@ -1182,7 +1212,11 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)bh * 16 + wid) * 8;
 #ifdef WKV6_STAMP
         for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
+#if WKV6_STAMP5 == 3
+        if (wid < 8) for (int i = 0; i < 4; ++i) d[(12 + (wid >> 1) - wid) * 8 + 4 * (wid & 1) + i] = poll_acc[i];  // records 12 .. 15: four events of waves 0 .. 7
+#else
         if (wid == 0 || wid == 4) for (int i = 0; i < 8; ++i) d[(12 + (wid >> 2) - wid) * 8 + i] = poll_acc[i];   // records 12 / 13
+#endif
 #endif
         d[6] = clk1 - clk0;
         d[7] = rtc1 - rtc0;

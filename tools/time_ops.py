@@ -85,6 +85,7 @@ if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wav
     print("  producers 8-11 = [load wait, prep, load issue, barrier]")
     for wv in range(12):
         print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / ns):8.0f}" for k in range(6)))
-    print("  cycles inside tag polls per stage, by tag group [DA SC GA GB GC GD GE GF]: row wave 0 / column wave 4")
-    for rec in (12, 13):
+    print("  records 12 (row wave 0) / 13 (column wave 4), per stage.  -DWKV6_STAMP5=1: cycles inside the polls of tag group [DA SC GA GB GC GD GE GF];")
+    print("  -DWKV6_STAMP5=3: cycles since the start of the stage at  row: [GA settled, GB published, GC asked for, GC there]  column: [GA published, GB asked for, GB there, GC published]")
+    for rec in (12, 13, 14, 15):     # (STAMP5=3: record 12 + w // 2, slots 4 (w % 2) .. + 3 = the four events of wave w, w = 0 .. 7)
         print(f"  rec  {rec:2d}: " + "  ".join(f"{(d[rec, k].item() / ns):8.0f}" for k in range(8)))
