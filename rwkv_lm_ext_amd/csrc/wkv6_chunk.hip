@@ -111,7 +111,10 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 else pe[tt] = buf_load16f(rs_w, iw * 4);
             }
         };
-        // `next`: group whose loads are requested as soon as the raw registers are consumed (WKV6_FWD_MIDLOAD experiment), -1: none
+        // `next`: group whose loads are requested as soon as the raw registers are consumed, -1: none.  (Requested behind the whole
+        // preparation they were in flight only for the barrier wait, ~1000 cycles of every group exposed; on its own the earlier request
+        // gained nothing -- the consumers' exposed LDS round trips took the time over -- together with their up-front operand requests
+        // 2-3 %: profiles/r04_fwd_prefetch.txt.)
         auto prep_group = [&](int grp, int buf, int next) {
             char* const bb = smem + buf * GRP_BYTES + wv * BLK_BYTES;
             float r[4][4], k[4][4], cs[4][4];
@@ -150,9 +153,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 }
                 *reinterpret_cast<uint2*>(bb + A_V * ARR + (4 * tq + tt) * RSB + 8 * c4) = pv[tt];
             }
-#ifdef WKV6_FWD_MIDLOAD
             if (next >= 0) load_group(next);
-#endif
             float pre[4], c8[4], c16[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -229,9 +230,6 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         if (ngrp > 0) {
             load_group(0);
             prep_group(0, 0, ngrp > 1 ? 1 : -1);
-#ifndef WKV6_FWD_MIDLOAD
-            if (ngrp > 1) load_group(1);
-#endif
         }
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
@@ -244,9 +242,6 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             if (grp + 1 < ngrp) {
                 prep_group(grp + 1, (grp + 1) & 1, grp + 2 < ngrp ? grp + 2 : -1);
                 WKV6_T(ts2);
-#ifndef WKV6_FWD_MIDLOAD
-                if (grp + 2 < ngrp) load_group(grp + 2);
-#endif
             }
             WKV6_T(ts3);
             __syncthreads();
@@ -396,10 +391,36 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                     }
                 }
                 // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
+                // ALL of the block's LDS operands are requested here, in one go, and the scheduler may not sink them: left to itself hipcc
+                // issues each read right in front of its use, and with two waves on a SIMD every one of the ~8 round trips of a block
+                // was exposed (the consumers' 5.7 k cycles per group were LDS latency, not issue: profiles/r04_fwd_prefetch.txt).
                 const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);
+                [[maybe_unused]] uint4 scp = {};
+                [[maybe_unused]] float4 pm0[2] = {}, pm1[2] = {};
+                [[maybe_unused]] b8v pzh[2] = {}, pzl[2] = {};
+                if constexpr (!STATE_ONLY) {
+                    scp = *reinterpret_cast<const uint4*>(bb + OFF_SC + lane * 16);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        pm0[s] = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g) * 4);
+                        pm1[s] = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g + 4) * 4);
+                        const int off = x * RSB + (32 * s + 8 * g) * 2;
+                        pzh[s] = ld_b8(bb + A_RH * ARR + off);
+                        pzl[s] = ld_b8(bb + A_RL * ARR + off);
+                    }
+                }
+                s4v pkh[4], pkl[4];
+                float4 pd16[4], pdm[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    pkh[it] = tr_read(bb + A_KH * ARR + trow + tile_tr(it));
+                    pkl[it] = tr_read(bb + A_KL * ARR + trow + tile_tr(it));
+                    pd16[it] = *reinterpret_cast<const float4*>(bb + OFF_E16 + (tile_ch(it) + 8 * g) * 4);
+                    pdm[it] = *reinterpret_cast<const float4*>(bb + OFF_E16M8 + (tile_ch(it) + 8 * g) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!STATE_ONLY) {
                     // (1) masked transposed scores, prepared by the producer of this block
-                    const uint4 scp = *reinterpret_cast<const uint4*>(bb + OFF_SC + lane * 16);
                     const s4v sc_hi = __builtin_bit_cast(s4v, make_uint2(scp.x, scp.y));
                     const s4v sc_lo = __builtin_bit_cast(s4v, make_uint2(scp.z, scp.w));
                     // (2) y^T[j][a] = sum_b V[b][j] sc[b][a]
@@ -412,8 +433,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                     // (3) y^T[j][a] += sum_i (E8 S)[i][j] Rhat[a][i]; k-slot (s, g, e) <-> channel 32s + 8g + e
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const float4 m0 = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g) * 4);
-                        const float4 m1 = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g + 4) * 4);
+                        const float4 m0 = pm0[s], m1 = pm1[s];
                         const float t0[4] = {St[2 * s][0] * m0.x, St[2 * s][1] * m0.y, St[2 * s][2] * m0.z, St[2 * s][3] * m0.w};
                         const float t1[4] = {St[2 * s + 1][0] * m1.x, St[2 * s + 1][1] * m1.y,
                                              St[2 * s + 1][2] * m1.z, St[2 * s + 1][3] * m1.w};
@@ -422,8 +442,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                         split4(t1, h1, l1);
                         const b8v s_hi = __builtin_bit_cast(b8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
                         const b8v s_lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
-                        const int off = x * RSB + (32 * s + 8 * g) * 2;
-                        const b8v zh = ld_b8(bb + A_RH * ARR + off), zl = ld_b8(bb + A_RL * ARR + off);
+                        const b8v zh = pzh[s], zl = pzl[s];
                         yt = mfma32(s_hi, zh, yt);
                         yt = mfma32(s_hi, zl, yt);
                         yt = mfma32(s_lo, zh, yt);
@@ -462,13 +481,11 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 // (4) S[it] <- E16 (.) S[it] + E16m8 (.) (Khat^T V)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const s4v kh = tr_read(bb + A_KH * ARR + trow + tile_tr(it));
-                    const s4v kl = tr_read(bb + A_KL * ARR + trow + tile_tr(it));
+                    const s4v kh = pkh[it], kl = pkl[it];
                     f4v o = {0.f, 0.f, 0.f, 0.f};
                     o = mfma16(kh, vf, o);
                     o = mfma16(kl, vf, o);
-                    const float4 d16 = *reinterpret_cast<const float4*>(bb + OFF_E16 + (tile_ch(it) + 8 * g) * 4);
-                    const float4 dm = *reinterpret_cast<const float4*>(bb + OFF_E16M8 + (tile_ch(it) + 8 * g) * 4);
+                    const float4 d16 = pd16[it], dm = pdm[it];
                     St[it][0] = fmaf(d16.x, St[it][0], dm.x * o[0]);
                     St[it][1] = fmaf(d16.y, St[it][1], dm.y * o[1]);
                     St[it][2] = fmaf(d16.z, St[it][2], dm.z * o[2]);
