@@ -674,10 +674,15 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 if (grp == ngrp - 1) await4(TAG_GA, grp + 1);
                 WKV6_EV(0);
                 gvb[1] = take_gop(1);
-                asm volatile("" :: "v"(gvb[1]));               // (the operand reads have returned)
+                // released at once: the reads are in this wave's LDS queue, which is served in order, and the tag store cannot be moved
+                // above loads it may alias (their address is opaque to the compiler) -- no need to wait for their data here
                 publish(TAG_GB + wv, grp + 1);
                 WKV6_EV(1);
             }
+            // (second half of wkv6_bi: the first half's gr of both blocks, requested a pre-phase ahead of the sums they meet)
+            float old_gr[SBLK][4] = {}, old_gk[SBLK][4] = {}, old_gw[SBLK][4] = {};
+#pragma unroll
+            for (int blk = SBLK - 1; blk >= 0; --blk) fetch_old(0, rs_gr, grp * STG + blk * BLK + x, REV_R, 16 * wv + 4 * g, old_gr[blk]);
             // then, so that it is there long before the others ask for it:
             if (wv >= 2) {   // this wave's dA tiles of the stage: block wv - 2, both orientations (tile 2 blk: dA[a][b], lane col b; 2 blk + 1:
                              // dA^T[b][a], lane col a) from one pair of operand reads.  Row waves 0 and 1 make the score tiles instead.
@@ -757,8 +762,6 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const rb = rpart(grp, blk);
                 const char* const kb = kpart(grp, blk);
-                float old_gr[4] = {0.f, 0.f, 0.f, 0.f};
-                fetch_old(0, rs_gr, grp * STG + blk * BLK + x, REV_R, 16 * wv + 4 * g, old_gr);
                 b8v gyr[2];                                      // gy [token x][32s + 8g .. +7]: the B operand of accs
 #pragma unroll
                 for (int s = 0; s < 2; ++s) gyr[s] = ld_b8(rb + R_GY * ARR + x * RSB + (32 * s + 8 * g) * 2);
@@ -815,11 +818,17 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         gu_acc[q] = fmaf(vg * rv[q], kv[q], gu_acc[q]);
                         at[blk][q] = rv[q] * dq;
                     }
-                    held_gr[blk] = emit(0, grp, blk, REV_R, o_gr, old_gr);
+                    held_gr[blk] = emit(0, grp, blk, REV_R, o_gr, old_gr[blk]);
                 }
             }
             WKV6_T(ts3);
             // the next stage's checkpoint: the state registers of this stage are dead from here on
+            // (... and its gk, gw, a chain ahead)
+#pragma unroll
+            for (int blk = SBLK - 1; blk >= 0; --blk) {
+                fetch_old(1, rs_gk, grp * STG + blk * BLK + x, REV_K, 16 * wv + 4 * g, old_gk[blk]);
+                fetch_old(3, rs_gw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw[blk]);
+            }
             WKV6_T5(2, tp0);
             if (grp > 0) request_ckpt(grp - 1);
             WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
@@ -839,9 +848,6 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const rb = rpart(grp, blk);
                 const char* const kb = kpart(grp, blk);
-                float old_gk[4] = {0.f, 0.f, 0.f, 0.f}, old_gw[4] = {0.f, 0.f, 0.f, 0.f};
-                fetch_old(1, rs_gk, grp * STG + blk * BLK + x, REV_K, 16 * wv + 4 * g, old_gk);
-                fetch_old(3, rs_gw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw);
                 f4v acck = {0.f, 0.f, 0.f, 0.f};
                 [[maybe_unused]] f4v Oi[4];
                 [[maybe_unused]] float e8x = 0.f, e16x = 0.f;
@@ -906,8 +912,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         o_gw[q] = (Rc[q] + (sfx[q] - dl[q]) - bt[q]) * lwv[q];
                         Rc[q] += total;
                     }
-                    put(1, rs_gk, grp, blk, REV_K, emit(1, grp, blk, REV_K, o_gk, old_gk));
-                    put(3, rs_gw, grp, blk, REV_W, emit(3, grp, blk, REV_W, o_gw, old_gw));
+                    put(1, rs_gk, grp, blk, REV_K, emit(1, grp, blk, REV_K, o_gk, old_gk[blk]));
+                    put(3, rs_gw, grp, blk, REV_W, emit(3, grp, blk, REV_W, o_gw, old_gw[blk]));
                 }
                 // ---- (SPLIT) G[i = 16wv + x][:] <- E16 G + E8 (Rhat^T gy)
                 if constexpr (SPLIT) {
@@ -1078,6 +1084,9 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     GJ[it][3] = fmaf(d16.w, GJ[it][3], d8.w * o[3]);
                 }
             }
+            float old_gv[SBLK][4] = {};                            // (second half of wkv6_bi: the first half's gv, a pre-phase ahead)
+#pragma unroll
+            for (int blk = SBLK - 1; blk >= 0; --blk) fetch_old(2, rs_gv, grp * STG + blk * BLK + x, REV_V, 16 * wv + 4 * g, old_gv[blk]);
             // ---- pre-phase: everything that does not depend on G
             if (SPLIT && wv < SBLK) {   // (no row waves in this workgroup) this wave's score tile of the stage: block wv
                 const char* const rb = rpart(grp, wv);
@@ -1140,8 +1149,6 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const kb = kpart(grp, blk);
-                float old_gv[4] = {0.f, 0.f, 0.f, 0.f};
-                fetch_old(2, rs_gv, grp * STG + blk * BLK + x, REV_V, 16 * wv + 4 * g, old_gv);
                 f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -1163,7 +1170,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 acc += accp[blk];
                 {
                     float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-                    held_gv[blk] = emit(2, grp, blk, REV_V, o, old_gv);
+                    held_gv[blk] = emit(2, grp, blk, REV_V, o, old_gv[blk]);
                 }
                 // ---- (SPLIT) G[:][j = 16wv + x] <- E16 G + E8 (Rhat^T gy)
                 if constexpr (SPLIT) {
