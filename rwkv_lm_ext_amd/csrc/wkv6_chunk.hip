@@ -264,6 +264,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 else io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.s0) + so_, t4);
             }
             St[it] = f4v{t4[0], t4[1], t4[2], t4[3]};
+            asm volatile("" : "+v"(St[it]));                       // (an entry state still in flight is waited for here, not inside the loop)
         }
         int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read, natural columns (this wave's V tile)
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
@@ -278,24 +279,39 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         const int segs = a.ckpt_segs > 1 ? a.ckpt_segs : 1;
         const long ck_slot0 = ((long)((b / segs) * a.H + h) * segs + b % segs) * nst;
         const rsrc_t rs_ck = make_rsrc(a.ckpt ? a.ckpt + ck_slot0 * (HEAD * HEAD) : nullptr, a.ckpt ? nst * 16384u : 0u);
-        // ACC (second half of wkv6_bi): the addend of a block is requested one block ahead, so that its HBM latency runs under
-        // the previous block's MFMAs instead of in front of the store
+        // ACC (second half of wkv6_bi): the addends of a whole group are requested a group ahead, as raw bits, into a second register
+        // set (handed over at the end of the group).  They used to be requested one block ahead through a two-way branch (fp32 side
+        // buffer / bf16 output) whose conversion made hipcc wait for each load right behind its issue: a full HBM latency per block
+        // (profiles/r04_bi_acc_prefetch.txt).  The block loop is unrolled for this instantiation: static register indices.
         // (wkv6_bi's halves go through buffer resources over the row's first ntok tokens like the plain path: tokens past the end
         // read zero / are dropped by the hardware -- no per-lane predicates, no 64-bit address arithmetic)
-        float acc_old[4] = {0.f, 0.f, 0.f, 0.f};
         const unsigned nb_y = (!STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * a.C : 0u;
         const rsrc_t rs_yf = make_rsrc(a.y_f32 ? a.y_f32 + base : nullptr, (a.y_f32 && !STATE_ONLY && ntok > 0) ? nb_y * 4u + 256u : 0u);
-        auto acc_fetch = [&](int p) {
-            const unsigned idx = (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g);
-            if (a.y_f32) {
-                const float4 t = buf_load16f(rs_yf, idx * 4u);
-                acc_old[0] = t.x; acc_old[1] = t.y; acc_old[2] = t.z; acc_old[3] = t.w;
-            } else {
-                const uint2 t = buf_load8(rs_y, idx * 2u);
-                acc_old[0] = bf_lo(t.x); acc_old[1] = bf_hi(t.x); acc_old[2] = bf_lo(t.y); acc_old[3] = bf_hi(t.y);
+        [[maybe_unused]] uint4 acc_cur[NBLK] = {}, acc_nxt[NBLK] = {};
+        auto acc_request = [&](int grp_, uint4 (&dst)[NBLK]) {
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) {
+                const unsigned idx = (unsigned)(tokmap(grp_ * GRP + blk * BLK + x, REV_Y) * a.C + 16 * wv + 4 * g);
+                if (a.y_f32) {
+                    const float4 t = buf_load16f(rs_yf, idx * 4u);
+                    dst[blk] = make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w));
+                } else {
+                    const uint2 t = buf_load8(rs_y, idx * 2u);
+                    dst[blk] = make_uint4(t.x, t.y, 0u, 0u);
+                }
             }
         };
-        if constexpr (ACC) acc_fetch(x);
+        auto acc_add = [&](const uint4& r, float (&o)[4]) {
+            if (a.y_f32) { o[0] += __uint_as_float(r.x); o[1] += __uint_as_float(r.y); o[2] += __uint_as_float(r.z); o[3] += __uint_as_float(r.w); }
+            else { o[0] += bf_lo(r.x); o[1] += bf_hi(r.x); o[2] += bf_lo(r.y); o[3] += bf_hi(r.y); }
+        };
+        if constexpr (ACC) {
+            acc_request(0, acc_cur);
+            // (waited for here, not at the first use inside the loop -- where the wait, sized for the loop's first entry, would also
+            //  cover the next group's requests every time round: wkv6_chunk_bwd12k.hip has the same note)
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) asm volatile("" : "+v"(acc_cur[blk].x), "+v"(acc_cur[blk].y), "+v"(acc_cur[blk].z), "+v"(acc_cur[blk].w));
+        }
         // GN epilogue state: this group's y (bf16-rounded) and gate per block, the channel's affine parameters
         float gn_y[NBLK][4], gn_ga[4] = {1.f, 1.f, 1.f, 1.f}, gn_be[4] = {0.f, 0.f, 0.f, 0.f};
         uint2 gn_g[NBLK];
@@ -338,6 +354,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         __syncthreads();
         for (int grp = 0; grp < ngrp; ++grp) {
             WKV6_T(ts0);
+            if constexpr (ACC) acc_request(grp + 1, acc_nxt);     // (past the last group: past the end of the resource, reads zero)
 
             // Rolled (runtime trip count): a fully unrolled 4-block body is no faster.  -DWKV6_FWD_UNROLL builds the unrolled
             // body for tools/check_unrolled_fwd.sh (the wrong y that build once produced was the mixed-shape
@@ -345,7 +362,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 #ifdef WKV6_FWD_UNROLL
             constexpr bool unrolled = true;
 #else
-            constexpr bool unrolled = GN;                         // the GN epilogue keeps per-block values in registers: static indices
+            constexpr bool unrolled = GN || ACC;                  // the GN epilogue and the ACC addends keep per-block values in registers: static indices
 #endif
             // blocks past the end are neutral (zero-filled operands) in the unrolled form
             const int nb = unrolled ? NBLK : min(NBLK, (ntok - grp * GRP + BLK - 1) / BLK);
@@ -468,11 +485,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                             }
                         } else {
                             const unsigned idx = (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g);
-                            if constexpr (ACC) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) o[q] += acc_old[q];      // fetched a block ago
-                                acc_fetch(p + BLK);                                   // the next block's addend: a block's work to arrive
-                            }
+                            if constexpr (ACC) acc_add(acc_cur[blk], o);          // requested a group ago
                             if (!ACC && a.y_f32) buf_store16f(rs_yf, idx * 4u, o);
                             else buf_store8(rs_y, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
                         }
@@ -496,6 +509,10 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                     for (int wb = 0; wb < 4; ++wb)
                         __builtin_amdgcn_raw_buffer_store_b128(ckd[wb], rs_ck, ck_off + wb * 4096, 0, 2 /* slc: streaming */);
                 }
+            }
+            if constexpr (ACC) {
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) acc_cur[blk] = acc_nxt[blk];
             }
             WKV6_T(ts1);
             __syncthreads();
