@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Guard for the round-4 finding: no `s_waitcnt vmcnt(0)` inside the stage loops of the consuming roles.
+
+    python tools/check_waitcnt.py          # compiles wkv6_chunk_bwd12k.hip to gfx950 ISA (~15 s) and prints the waits per loop
+
+A loop-carried register whose first value is a load still in flight at loop entry makes hipcc place the wait at the register's first
+use INSIDE the loop, sized for the first entry (vmcnt(0)); in steady state that wait then covers whatever the wave has just requested
+and the acknowledgement of its last stores, every stage.  The row and column waves' loops (the ones that store gradients) must wait
+only with counted vmcnt(N > 0); the producers' loop legitimately drains its queue (its oldest requests are the ones it needs).
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "rwkv_lm_ext_amd", "csrc", "wkv6_chunk_bwd12k.hip")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-w", "-S", "--cuda-device-only"]
+KERNELS = ("chunk_bwd12k_kernelILb1ELi0ELb0EEE", "chunk_bwd12k_kernelILb0ELi0ELb0EEE")    # raw-w / fp32-ew, plain stores, one workgroup per pair
+
+
+def stage_loops(asm, kernel_substr):
+    """[(header label, #buffer stores, #buffer loads, [vmcnt values waited for])] of the depth-1 loops of one kernel."""
+    for f in re.split(r"\n(?=_Z[\w]+:)", asm):
+        name = f.split(":", 1)[0]
+        if kernel_substr in name and name.startswith("_Z"):
+            break
+    else:
+        raise SystemExit(f"no function matching {kernel_substr}")
+    parent = {m.group(1): m.group(2) for m in re.finditer(r"^\.L(BB\d+_\d+):\s*;\s*Parent Loop (BB\d+_\d+) Depth=1", f, re.M)}
+    loops, cur = {}, None
+    for line in f.split("\n"):
+        m = re.match(r"^\.L(BB\d+_\d+):\s*(;.*)?$", line)
+        if m:
+            label, c = m.group(1), m.group(2) or ""
+            hdr = re.search(r"Header=(BB\d+_\d+) Depth=(\d+)", c)
+            if "Loop Header: Depth=1" in c:
+                cur = label
+            elif label in parent:
+                cur = parent[label]
+            elif hdr:
+                cur = parent.get(hdr.group(1), hdr.group(1))
+            else:
+                cur = None
+            continue
+        if cur is None or not line.startswith("\t"):
+            continue
+        d = loops.setdefault(cur, {"stores": 0, "loads": 0, "waits": []})
+        op = line.strip().split()[0]
+        if op.startswith("buffer_store"):
+            d["stores"] += 1
+        elif op.startswith("buffer_load"):
+            d["loads"] += 1
+        elif op == "s_waitcnt":
+            w = re.search(r"vmcnt\((\d+)\)", line)
+            if w:
+                d["waits"].append(int(w.group(1)))
+    return [(k, v["stores"], v["loads"], v["waits"]) for k, v in loops.items()]
+
+
+def check(verbose=False):
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.check_call(["hipcc"] + FLAGS + ["-o", out, SRC], stderr=subprocess.DEVNULL)
+        asm = open(out).read()
+    bad = []
+    for kern in KERNELS:
+        consuming = 0
+        for label, stores, loads, waits in stage_loops(asm, kern):
+            if stores == 0:
+                continue                                   # producers (loads only), polls, tails
+            consuming += 1
+            if verbose:
+                print(f"{kern}: loop {label}: {stores} buffer stores, {loads} buffer loads, vmcnt waits {waits}")
+            if 0 in waits:
+                bad.append((kern, label, waits))
+        if consuming < 2:
+            bad.append((kern, "expected the row and the column waves' stage loops", consuming))
+    return bad
+
+
+if __name__ == "__main__":
+    problems = check(verbose=True)
+    for p in problems:
+        print("PROBLEM:", p)
+    sys.exit(1 if problems else 0)

@@ -108,14 +108,17 @@ def role_of(d, kind):
     if kind == "bwd":
         if exps >= 16 and loads >= 4:
             return "producer"
-        if stores >= 5:
+        if stores >= 3:
             return "row"
         if stores >= 1:
             return "column"
     else:
+        mf = d["cls"]["mfma"] + d["cls2"]["mfma"]
+        if exps >= 16 and mf >= 16:
+            return "both"             # hipcc merged the two roles' group loops into one (role branch inside): counted together
         if exps >= 16:
             return "producer"
-        if d["cls"]["mfma"] + d["cls2"]["mfma"] >= 8:
+        if mf >= 8:
             return "consumer"
     return None
 
@@ -126,7 +129,7 @@ def table(asm, kernel_substr, kind, unit_tokens, blocks_per_iter=1):
     for hdr, d in loops.items():
         role = role_of(d, kind)
         # inner (depth-2) loops: the forward consumers' block loop runs 4 times per group; the backward's are tag polls (once)
-        mult = 4 if (kind == "fwd" and role == "consumer") else 1
+        mult = 4 if (kind == "fwd" and role in ("consumer", "both")) else 1
         c = collections.Counter(d["cls"])
         for k, v in d["cls2"].items():
             c[k] += mult * v
@@ -149,8 +152,8 @@ def main():
             out = os.path.join(tmp, src + ".s")
             subprocess.check_call(["hipcc"] + FLAGS + ["-o", out, os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
             res[src] = open(out).read()
-    fwd = table(res["wkv6_chunk.hip"], "chunk_fwd_kernelILb1ELb0ELb0ELb0E", "fwd", 64)
-    bwd = table(res["wkv6_chunk_bwd12k.hip"], "chunk_bwd12k_kernelILb1ELi0E", "bwd", 32)
+    fwd = table(res["wkv6_chunk.hip"], "chunk_fwd_kernelILb1ELb0ELb0ELb0EEE", "fwd", 64)
+    bwd = table(res["wkv6_chunk_bwd12k.hip"], "chunk_bwd12k_kernelILb1ELi0ELb0EEE", "bwd", 32)
     # a SIMD hosts one wave of every role: what it must issue per loop iteration
     for label, rows, tokens, waves in (("forward", fwd, 64, 2), ("backward", bwd, 32, 3)):
         by = {}
