@@ -151,7 +151,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
 #endif
     const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);
-    // wkv6_bi's halves: the first (GEN == 1) writes its four gradients into fp32 side buffers (or, without them, the outputs), the
+    // wkv6_bi's halves: the first (GEN == 1) writes its four gradients into fp32 side buffers (always there: checked at launch), the
     // second (GEN == 2) requests them ahead of the work whose result they meet, adds and rounds once.  Side buffers and outputs alike
     // go through buffer resources over the row's first ntok tokens: tokens past the end read zero / are dropped by the hardware.
     const unsigned nbytes4 = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 4u + 256u : 0u;
@@ -162,13 +162,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     auto fetch_old = [&](int which, const rsrc_t& rs, int p, unsigned bit, int ch, float (&old)[4]) {
         if constexpr (GEN == 2) {
             const unsigned idx = (unsigned)(tokmap(p, bit) * a.C + ch);
-            if (a.g_f32[which]) {
-                const float4 t = buf_load16f(rs_side[which], idx * 4u);
-                old[0] = t.x; old[1] = t.y; old[2] = t.z; old[3] = t.w;
-            } else {
-                const uint2 t = buf_load8(rs, idx * 2u);
-                old[0] = bf_lo(t.x); old[1] = bf_hi(t.x); old[2] = bf_lo(t.y); old[3] = bf_hi(t.y);
-            }
+            const float4 t = buf_load16f(rs_side[which], idx * 4u);   // (the halves of wkv6_bi always meet in the fp32 side buffers: checked at launch)
+            old[0] = t.x; old[1] = t.y; old[2] = t.z; old[3] = t.w;
         }
     };
 #ifdef WKV6_STAMP
@@ -205,7 +200,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #endif
     [[maybe_unused]] uint2 held_st[4] = {};
     auto put = [&](int which, const rsrc_t& rs, int stg, int blk, unsigned bit, uint2 v) {   // this lane: token x_ of the block, channels 16 wv + 4 g_ .. + 3
-        if (GEN == 1 && a.g_f32[which]) return;                    // (went to the fp32 side buffer in emit)
+        if constexpr (GEN == 1) return;                            // (went to the fp32 side buffer in emit)
 #if WKV6_STORE_MODE == 0
         buf_store8(rs, (unsigned)(tokmap(stg * STG + blk * BLK + x_, bit) * a.C + 16 * wv + 4 * g_) * 2u, v);
 #else
@@ -220,11 +215,9 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // bf16 quad for the staging area
     auto emit = [&](int which, int stg, int blk, unsigned bit, float (&o)[4], const float (&old)[4]) -> uint2 {
         if constexpr (GEN == 1) {
-            if (a.g_f32[which]) {
-                const unsigned idx = (unsigned)(tokmap(stg * STG + blk * BLK + x_, bit) * a.C + 16 * wv + 4 * g_);
-                buf_store16f(rs_side[which], idx * 4u, o);
-                return make_uint2(0u, 0u);
-            }
+            const unsigned idx = (unsigned)(tokmap(stg * STG + blk * BLK + x_, bit) * a.C + 16 * wv + 4 * g_);
+            buf_store16f(rs_side[which], idx * 4u, o);
+            return make_uint2(0u, 0u);
         }
         if constexpr (GEN == 2) {
 #pragma unroll
@@ -640,10 +633,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         // sizes the one s_waitcnt at the loop head for the worse of its two entries, and on first entry only the other three checkpoint
         // loads follow -- vmcnt(3 .. 0) would then wait, every stage, for the stores of the stage before to be acknowledged.  Three
         // stores that the bounds check drops give the first entry the same queue.
-        if constexpr (GEN != 1) {
+        {   // (first half of wkv6_bi: four fp32 side stores -- gk, gw of both blocks -- follow a stage's checkpoint request)
             const rsrc_t rs_none = make_rsrc(static_cast<bf16_t*>(nullptr), 0u);
 #pragma unroll
-            for (int i = 0; i < (WKV6_STORE_MODE == 0 ? 6 : 3); ++i) buf_store16(rs_none, 16u * i, make_uint4(0u, 0u, 0u, 0u));   // (distinct: identical ones are merged)
+            for (int i = 0; i < (GEN == 1 ? 4 : WKV6_STORE_MODE == 0 ? 6 : 3); ++i) buf_store16(rs_none, 16u * i, make_uint4(0u, 0u, 0u, 0u));   // (distinct: identical ones are merged)
         }
 
         __syncthreads();                                          // first stage image is ready
@@ -1271,8 +1264,10 @@ template <bool W_RAW, int GEN> hipError_t launch_bwd12k_inst(const ScanArgs& a, 
 }
 template <bool W_RAW> hipError_t launch_bwd12k_variant(const ScanArgs& a, hipStream_t st)
 {
-    if (a.accumulate) return launch_bwd12k_inst<W_RAW, 2>(a, st);
+    const bool side = a.g_f32[0] && a.g_f32[1] && a.g_f32[2] && a.g_f32[3];
+    if (a.accumulate) return side ? launch_bwd12k_inst<W_RAW, 2>(a, st) : hipErrorInvalidValue;   // the halves of wkv6_bi meet in fp32 side buffers
     const bool first_half = a.zero_tail || a.g_f32[0] || a.g_f32[1] || a.g_f32[2] || a.g_f32[3];
+    if (first_half && !side) return hipErrorInvalidValue;
     return first_half ? launch_bwd12k_inst<W_RAW, 1>(a, st) : launch_bwd12k_inst<W_RAW, 0>(a, st);
 }
 
