@@ -212,7 +212,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #endif
     };
     // the result of one block: fp32 side buffer (first half of wkv6_bi: 64-byte pieces, 16 bytes per lane as they are) or the packed
-    // bf16 quad for the staging area
+    // bf16 quad for `put`
     auto emit = [&](int which, int stg, int blk, unsigned bit, float (&o)[4], const float (&old)[4]) -> uint2 {
         if constexpr (GEN == 1) {
             const unsigned idx = (unsigned)(tokmap(stg * STG + blk * BLK + x_, bit) * a.C + 16 * wv + 4 * g_);
@@ -750,7 +750,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
             f4v ackp[SBLK];
             float at[SBLK][4], vgs[SBLK];
-            uint2 held_gr[SBLK];                                  // gr waits for this wave's stripe of the staging area (free behind take_gop(0))
+            uint2 held_gr[SBLK];                                  // gr of both blocks, stored behind take_gop(0) (after the checkpoint request: keeps the
+                                                                  // vector-memory queue's order loads-then-stores, see the dummy stores in front of the loop)
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
                 const char* const rb = rpart(grp, blk);
