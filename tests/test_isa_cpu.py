@@ -1,7 +1,9 @@
 """ISA-level guards that need no GPU: hipcc cross-compiles gfx950 here.
 
 Round 4: the backward's consuming roles must not wait with `s_waitcnt vmcnt(0)` inside their stage loops -- that wait
-made every stage wait for its own fresh requests and for the acknowledgement of the previous stage's stores (-9 % when removed).
+made every stage wait for its own fresh requests and for the acknowledgement of the previous stage's stores (-9 % when removed) --
+and the row waves' wait-free releases of the published G operand (tags GB / GD) must stay behind the eight transposed reads of it
+in every instantiation (the LDS serves a wave's requests in order; the compiler must not move the tag store above them).
 """
 import os
 import shutil

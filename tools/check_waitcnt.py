@@ -59,12 +59,41 @@ def stage_loops(asm, kernel_substr):
     return [(k, v["stores"], v["loads"], v["waits"]) for k, v in loops.items()]
 
 
+# The row waves release the published G operand (tags GB / GD, LDS byte offsets 304 / 464 of the tag rows) right behind their reads of
+# it, without waiting for the data: correct because the LDS serves a wave's requests in order AND the compiler keeps the tag store
+# behind the eight transposed reads (it may alias them).  This lists, for every tag store, how many of those reads precede it closely.
+RELEASE_TAG_OFFSETS = (304, 464)
+
+
+def release_order(asm, kernel_substr, window=80):
+    for f in re.split(r"\n(?=_Z[\w]+:)", asm):
+        name = f.split(":", 1)[0]
+        if kernel_substr in name and name.startswith("_Z"):
+            break
+    else:
+        raise SystemExit(f"no function matching {kernel_substr}")
+    lines = f.split("\n")
+    out = []
+    for i, line in enumerate(lines):
+        m = re.search(r"ds_write_b32 .*offset:(\d+)\b", line)
+        if m and int(m.group(1)) in RELEASE_TAG_OFFSETS:
+            reads = sum(1 for x in lines[max(0, i - window):i] if x.strip().startswith("ds_read_b64_tr_b16"))
+            out.append((int(m.group(1)), reads))
+    return out
+
+
 def check(verbose=False):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
         subprocess.check_call(["hipcc"] + FLAGS + ["-o", out, SRC], stderr=subprocess.DEVNULL)
         asm = open(out).read()
     bad = []
+    for kern in KERNELS + ("chunk_bwd12k_kernelILb1ELi1ELb0EEE", "chunk_bwd12k_kernelILb1ELi2ELb0EEE", "chunk_bwd12k_pair_kernelILb1EEE"):
+        rel = release_order(asm, kern)
+        if verbose:
+            print(f"{kern}: operand releases (tag offset, transposed reads in the 80 lines before): {rel}")
+        if sorted(o for o, _ in rel) != sorted(RELEASE_TAG_OFFSETS) or any(n < 8 for _, n in rel):
+            bad.append((kern, "operand release not behind its eight reads", rel))
     for kern in KERNELS:
         consuming = 0
         for label, stores, loads, waits in stage_loops(asm, kern):
