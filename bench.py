@@ -34,7 +34,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r04_final_pmc.json")
 
 
 def pmc_from_file():
-    """Fallback for roofline.traffic / valu_busy: the committed rocprofv3 PMC passes of this round's kernels."""
+    """Fallback for roofline.traffic / valu_issue_share: the committed rocprofv3 PMC passes of this round's kernels."""
     try:
         with open(PMC_FILE) as f:
             return json.load(f)["kernels"]
@@ -49,22 +49,24 @@ def add_counter_rows(rows, acc):
     per_dispatch = {}
     for row in rows:
         kn = row["Kernel_Name"]
-        key = "chunk_bwd12k_kernel" if "chunk_bwd12k" in kn else "chunk_bwd12_kernel" if "chunk_bwd12" in kn else \
-            "chunk_bwd64_kernel" if "chunk_bwd64" in kn else "chunk_fwd_kernel" if "chunk_fwd_kernel" in kn else None
+        key = "chunk_bwd12k_kernel" if "chunk_bwd12k" in kn else "chunk_fwd_kernel" if "chunk_fwd_kernel" in kn else None
         if key:
             id_ = (key, row["Counter_Name"], row["Dispatch_Id"])
             per_dispatch[id_] = per_dispatch.get(id_, 0.0) + float(row["Counter_Value"])
     for (key, cname, _), val in per_dispatch.items():
         acc.setdefault(key, {}).setdefault(cname, []).append(val)
-    # whole passes (workloads of several launches per pass: wkv6_bi, infctx, two-level scans): every dispatch of this library's
-    # forward-side / backward-side kernels, summed
-    for row in rows:
-        kn = row["Kernel_Name"]
-        if "wkv6::" not in kn:
-            continue
-        side = "_pass_bwd" if ("bwd" in kn or "backward" in kn) else "_pass_fwd"
-        tot = acc.setdefault(side, {}).setdefault(row["Counter_Name"], [0.0])
-        tot[0] += float(row["Counter_Value"])
+    # whole passes (workloads of several launches per pass: wkv6_bi, infctx, two-level scans): every dispatch of this library's kernels
+    # between the phase markers the child launches (pmc_child: marker, forwards, marker, backwards, marker), summed per phase.  A
+    # backward's own state passes and scan helpers carry forward-style names: the phase, not the name, says whose traffic they are.
+    marks = sorted(int(row["Dispatch_Id"]) for row in rows if "pass_marker_kernel" in row["Kernel_Name"] and row["Counter_Name"] == rows[0]["Counter_Name"])
+    if len(marks) >= 3:
+        for row in rows:
+            kn, d = row["Kernel_Name"], int(row["Dispatch_Id"])
+            if "wkv6::" not in kn or "pass_marker_kernel" in kn or d < marks[0] or d > marks[2]:
+                continue                        # (anything in front of the first marker -- module load, self-tests -- belongs to no pass)
+            side = "_pass_fwd" if d < marks[1] else "_pass_bwd"
+            tot = acc.setdefault(side, {}).setdefault(row["Counter_Name"], [0.0])
+            tot[0] += float(row["Counter_Value"])
 
 
 def reduce_counters(acc):
@@ -131,7 +133,9 @@ def pmc_live(workload="wkv6", timeout_s=75):
 def under_profiler():
     """Is this process itself running under rocprofv3 / another preloaded tool?  Then no second profiler is started beneath it
     (the children would inherit the preload environment)."""
-    return any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    # (rocprofv3 exports ROCP_TOOL_LIBRARIES and preloads librocprofiler-sdk-tool.so for its child; a ROCPROFILER_* / ROCPROF_* path
+    # variable of the image or the user is not a profiler)
+    return "ROCP_TOOL_LIBRARIES" in os.environ or "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", "")
 
 
 PMC_CHILD_STEPS = 6
@@ -139,17 +143,34 @@ PMC_CHILD_STEPS = 6
 
 def pmc_child(workload):
     """The profiled child of pmc_live(): PMC_CHILD_STEPS forward + backward passes of the workload, nothing else."""
+    from rwkv_lm_ext_amd import wkv6_op
     fwd, bwd = build_workload(workload, torch.device("cuda", 0))[:2]
+    fwd()                                   # (checkpoints for the first backward; in front of the first marker: counted in no pass)
+    wkv6_op.pass_marker()
     for _ in range(PMC_CHILD_STEPS):
         fwd()
+    wkv6_op.pass_marker()
+    for _ in range(PMC_CHILD_STEPS):
         bwd()
+    wkv6_op.pass_marker()
     torch.cuda.synchronize()
 
 
-def valu_busy_of(c):
-    """SQ_ACTIVE_INST_VALU * 4 / (SIMDs * kernel cycles), GRBM_GUI_ACTIVE being summed over the 8 XCDs."""
+def valu_issue_share_of(c):
+    """Sum over a SIMD's resident waves of their VALU issue cycles / kernel cycles = SQ_ACTIVE_INST_VALU * 4 / (SIMDs * kernel cycles),
+    GRBM_GUI_ACTIVE being summed over the 8 XCDs.  NOT a pipe utilisation: the counter charges every VALU instruction 4 cycles
+    (8 for transcendental / permlane) whatever the instruction's real issue cost and however many waves share the SIMD -- it reads
+    1.75-1.9 for a full-rate stream at 2-4 waves per SIMD (profiles/r05_issue_floor.md).  Kept as an instruction-density figure."""
     try:
         return round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3)
+    except Exception:
+        return None
+
+
+def profiled_clock_ghz(c, ms):
+    """Effective shader clock of a PROFILED launch (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE / 8 XCDs / duration."""
+    try:
+        return round(c["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e-3) / 1e9, 3)
     except Exception:
         return None
 
@@ -217,7 +238,17 @@ def bench_dp_lora(args, rank, world, dev, dist):
             if n.endswith("lora_B"):
                 p.normal_(0.0, 0.01)
     msg_bytes = train_dp.grad_allreduce_bytes(model)
-    net = train_dp.wrap_ddp(model, dev) if dist is not None else model
+    if dist is None:
+        # one GPU: the same DDP wrapper over a one-rank RCCL group (hooks, bucket views and the all-reduce all execute)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    net = train_dp.wrap_ddp(model, dev)
     opt = torch.optim.AdamW(train_dp.trainable_parameters(model), lr=1e-5)
     total = args.steps + args.warmup + 1
     sampler = BucketBatchSampler([total * bs * world], [bs], rank, world)
@@ -398,7 +429,12 @@ def main():
         fwd()
         bwd()
     torch.cuda.synchronize()
+    # in-run shader clock: wave 0 of every workgroup of the plain chunked kernels stamps {s_memtime, s_memrealtime} at its start and
+    # end (four scalar instructions and two 8-byte stores per workgroup and launch, inside the timed region like everything else)
+    probe = wkv6_op.ClockProbe(dev, n_slots=1024)
     elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
+    clocks = probe.read()                 # the last forward / backward launch of the timed region
+    probe.close()
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
 
@@ -406,9 +442,7 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         units = tokens * C                                    # token-channels per step per GPU
         dom_name, dom_ms, dom_b = ("backward", bwd_ms, BWD_BYTES) if bwd_ms >= fwd_ms else ("forward", fwd_ms, FWD_BYTES)
-        dom_kernel = "chunk_fwd_kernel" if dom_name == "forward" else \
-            {"64": "chunk_bwd64_kernel"}.get(os.environ.get("WKV6_BWD", ""),
-                                                                                                  "chunk_bwd12k_kernel")
+        dom_kernel = "chunk_fwd_kernel" if dom_name == "forward" else "chunk_bwd12k_kernel"
         ach = units * dom_b / (dom_ms * 1e-3) / 1e9
 
         def traffic_of(kernel, side):
@@ -432,14 +466,19 @@ def main():
                        "math": "split-bf16 (hi+lo) MFMA operands, fp32 accumulate and state",
                        "tokens_per_gpu": tokens, "channels": C,
                        "parallelism": f"dp{world} (independent batches per GPU, no data-path collective)",
-                       "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4)},
+                       "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
+                       # in-kernel shader clock of the last timed launch of each kernel: d(s_memtime) / d(s_memrealtime) x 100 MHz,
+                       # median over workgroups (MI355X_MICROARCH.md, DVFS give-back item 6) -- for comparing numbers between boxes
+                       "fwd_clock_ghz": clocks.get("fwd_ghz"), "bwd_clock_ghz": clocks.get("bwd_ghz")},
             "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4),
                          "traffic": traffic_of(dom_kernel, "_pass_bwd" if dom_name == "backward" else "_pass_fwd"),
                          "traffic_source": pmc_source if (pmc.get(dom_kernel) or pmc.get("_pass_fwd")) else None,
                          "algorithmic_bytes_per_launch": units * dom_b, "avg_ms": round(dom_ms, 4),
-                         "valu_busy": valu_busy_of(pmc.get(dom_kernel, {}).get("counters", {}))},
+                         "valu_issue_share": valu_issue_share_of(pmc.get(dom_kernel, {}).get("counters", {})),
+                         "valu_issue_share_note": "sum of the resident waves' VALU issue cycles / kernel cycles (4 cycles charged per "
+                                                  "instruction): instruction density, not pipe occupancy (profiles/r05_issue_floor.md)"},
             "roofline_step": {"bound": "hbm", "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(step_ach / HBM_PEAK_GBPS, 4),
                               "algorithmic_bytes": units * step_bytes,

@@ -105,8 +105,8 @@ size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H);
 int wkv6_forward_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
                     const void* w, const void* u, const void* s0, void* s_out, void* y,
                     unsigned flags, void* stream);
-/* Same as wkv6_forward_ex, and additionally stores the forward state every 64 tokens (every 32 where two workgroups serve
- * a (batch, head) pair; fp32, wkv6_backward_workspace_bytes() bytes in all) into `ckpt` -- the activation checkpoint a following
+/* Same as wkv6_forward_ex, and additionally stores the forward state every 64 tokens (fp32, 4 B per token-channel,
+ * wkv6_backward_workspace_bytes() bytes in all) into `ckpt` -- the activation checkpoint a following
  * wkv6_backward_ex(..., workspace = ckpt, flags | WKV6_CKPT_VALID) consumes.  bf16 I/O, chunked kernels only;
  * returns WKV6_EUNSUPPORTED for WKV6_IO_F32 / WKV6_ALGO_SCAN. */
 int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* k, const void* v,
@@ -220,6 +220,16 @@ int wkv6_sigmul_backward(long n, const void* r, const void* kv, const void* dout
  * that both backward kernels run -- (forward and backward, all outputs within 2 bf16 ulps of the tensor scale, 4 for gw).
  * Returns 0 when it passes, WKV6_ESELFTEST (or the number of failed primitive checks) otherwise. */
 int wkv6_selftest(void* stream);
+/* Measurement aids (bench.py; no effect on results).
+ * wkv6_set_clock_buffer: while `buf` (device memory, 2 * n_slots * 4 uint64) is set, wave 0 of the first n_slots workgroups of every
+ * chunked forward launch writes {s_memtime, s_memrealtime} at its start and its end into buf[slot * 4 .. + 3], and of every chunked
+ * backward launch into buf[(n_slots + slot) * 4 .. + 3]: the in-kernel shader clock of a launch is d(s_memtime) / d(s_memrealtime)
+ * x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  buf = NULL (the default) switches it off: the kernels then execute one
+ * scalar branch for it and no stamp.  Process-wide; not for use from concurrent streams.
+ * wkv6_pass_marker: launches an empty kernel named wkv6::pass_marker_kernel on `stream`: a phase boundary in a profiler's
+ * dispatch list. */
+void wkv6_set_clock_buffer(void* buf, int n_slots);
+int wkv6_pass_marker(void* stream);
 /* "major.minor" of the library. */
 const char* wkv6_amd_version(void);
 

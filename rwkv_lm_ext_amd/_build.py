@@ -10,7 +10,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "librwkv6_amd.so")
-SOURCES = ["wkv6_scan.hip", "wkv6_chunk.hip", "wkv6_chunk_bwd12k.hip", "wkv6_chunk_bwd64.hip", "wkv6_mix.hip", "wkv6_api.hip"]
+SOURCES = ["wkv6_scan.hip", "wkv6_chunk.hip", "wkv6_chunk_bwd12k.hip", "wkv6_mix.hip", "wkv6_api.hip"]
 HEADERS = ["wkv6_common.h", "wkv6_scan.h", "wkv6_chunk.h", os.path.join("..", "..", "include", "wkv6_amd.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-Wall", "-Wno-unused-function"]
 

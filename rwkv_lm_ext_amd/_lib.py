@@ -59,6 +59,8 @@ SIGNATURES = {
     "wkv6_sigmul_forward": (_I, [_L] + [_VP] * 4),
     "wkv6_sigmul_backward": (_I, [_L] + [_VP] * 6),
     "wkv6_selftest": (_I, [_VP]),
+    "wkv6_set_clock_buffer": (None, [_VP, _I]),
+    "wkv6_pass_marker": (_I, [_VP]),
     "wkv6_amd_version": (ctypes.c_char_p, []),
 }
 
@@ -91,7 +93,10 @@ def load():
             if not os.path.exists(path):
                 raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
             lib = ctypes.CDLL(path)
+            explicit = bool(os.environ.get("RWKV_AMD_LIB"))
             for name, (res, args) in SIGNATURES.items():
+                if explicit and name in ("wkv6_set_clock_buffer", "wkv6_pass_marker") and not hasattr(lib, name):
+                    continue                     # an A/B library of an earlier round: the measurement aids are newer than it
                 fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
                 fn.restype = res
                 fn.argtypes = args

@@ -104,31 +104,6 @@ __global__ void length_order_kernel(const int* __restrict__ lens, int* __restric
 
 int to_rc(hipError_t e) { return e == hipSuccess ? WKV6_OK : (int)e; }
 
-// What a checkpoint buffer holds.  Spacing and layout of the checkpoints follow from switches that are read per call (WKV6_BWD,
-// WKV6_SPLIT: chunk_ckpt_plan); a backward that is told "the forward filled this buffer" (WKV6_CKPT_VALID) must not read a
-// 32-token forward-order image as a 64-token row-order one because a switch changed in between.  Every forward that writes
-// checkpoints notes (buffer, spacing, layout) here; a CKPT_VALID backward whose plan differs from the note rebuilds the
-// checkpoints with its own state pass instead of trusting them.  A buffer without a note is trusted (as before).
-struct CkptNote { const void* ptr; int tok, fmt; };
-std::mutex g_ckpt_mu;
-CkptNote g_ckpt_notes[128] = {};
-unsigned g_ckpt_next = 0;
-void ckpt_note(const void* ptr, const ScanArgs& a)
-{
-    if (!ptr) return;
-    std::lock_guard<std::mutex> lk(g_ckpt_mu);
-    for (CkptNote& n : g_ckpt_notes)
-        if (n.ptr == ptr) { n.tok = a.ckpt_tok; n.fmt = a.ckpt_fmt; return; }
-    g_ckpt_notes[g_ckpt_next++ % 128] = CkptNote{ptr, a.ckpt_tok, a.ckpt_fmt};
-}
-bool ckpt_matches(const void* ptr, const ScanArgs& a)
-{
-    std::lock_guard<std::mutex> lk(g_ckpt_mu);
-    for (const CkptNote& n : g_ckpt_notes)
-        if (n.ptr == ptr) return n.tok == a.ckpt_tok && n.fmt == a.ckpt_fmt;
-    return true;
-}
-
 // ---- forward over few, long sequences (inference prefill: B*H << CUs): two-level scan over T.  The sequence is cut into S
 // segments that run as S times as many workgroups:
 //   1. state pass per segment from a zero state: A_seg = the segment's own contribution to the state, and the per-channel sum
@@ -179,17 +154,6 @@ int tsplit_segments(const ScanArgs& a)
     while (2 * S <= 16 && (long)a.B * a.H * 2 * S <= cus && a.T % (64 * 2 * S) == 0 && a.T / (2 * S) >= 512) S *= 2;
     return S >= 4 ? S : 1;      // two segments do not pay for the extra state pass (two workgroups per pair serve that case)
 }
-// A call that runs as a two-level scan runs on B * S rows with one workgroup each: its checkpoints are 64 tokens apart in row
-// order whatever the plan of the unsplit shape says (unless an A/B switch pins another backward kernel: then only the forward is
-// segmented and the backward walks whole sequences, as in rounds 2-3).
-bool tsplit_plan(ScanArgs& a, int S)
-{
-    if (S <= 1 || getenv("WKV6_BWD")) return false;
-    a.ckpt_tok = 64;
-    a.ckpt_fmt = CKPT_ROW_ORDER;
-    return true;
-}
-
 // segment entry states of a two-level forward: state pass per segment from zero (A, dsum), chained by tsplit_combine_kernel
 hipError_t tsplit_entry_states(const ScanArgs& a, int S, float* A, float* Sin, float* dsum, hipStream_t st)
 {
@@ -207,7 +171,6 @@ hipError_t chunk_forward(const ScanArgs& a_, hipStream_t st)
     ScanArgs a = a_;
     const int S = tsplit_segments(a);
     if (S <= 1) return launch_chunk_fwd(a, st);
-    tsplit_plan(a, S);
     const size_t nstate = (size_t)a.B * S * a.H * HEAD * HEAD;                 // floats
     const size_t ndsum = (size_t)a.B * S * a.H * 4 * HEAD;
     StreamScratch scratch;
@@ -287,7 +250,7 @@ hipError_t chunk_backward(const ScanArgs& a_, hipStream_t st)
 {
     ScanArgs a = a_;
     const int S = tsplit_segments(a);
-    if (S <= 1 || !tsplit_plan(a, S)) return launch_chunk_bwd(a_, st);
+    if (S <= 1) return launch_chunk_bwd(a_, st);
     const int Ts = a.T / S;
     const size_t nstate = (size_t)a.B * S * a.H * HEAD * HEAD, ndsum = (size_t)a.B * S * a.H * 4 * HEAD, nrow = (size_t)a.B * S * a.C;
     StreamScratch scratch;
@@ -341,9 +304,7 @@ hipError_t run_bwd(ScanArgs& a, unsigned flags, float* scratch, hipStream_t st)
         return launch_scan_bwd(a, flags & WKV6_IO_F32, st);
     }
     a.ckpt = scratch;
-    tsplit_plan(a, tsplit_segments(a));            // (a two-level call has its own checkpoint plan; chunk_backward decides the same way)
-    a.ckpt_valid = ((flags & WKV6_CKPT_VALID) && ckpt_matches(scratch, a)) ? 1 : 0;
-    if (!a.ckpt_valid) ckpt_note(scratch, a);      // the state pass of this call fills it
+    a.ckpt_valid = (flags & WKV6_CKPT_VALID) ? 1 : 0;
     return chunk_backward(a, st);
 }
 
@@ -356,9 +317,6 @@ ScanArgs base_args(int B, int T, int C, int H, const void* r, const void* k, con
     a.wkind = (flags & WKV6_W_RAW) ? 1 : 0;
     a.part_f32 = (flags & WKV6_PARTIALS_F32) ? 1 : 0;
     a.use_u = 1;
-    const CkptPlan plan = chunk_ckpt_plan(B * H);
-    a.ckpt_tok = plan.tok;
-    a.ckpt_fmt = plan.fmt;
     return a;
 }
 
@@ -369,13 +327,30 @@ namespace wkv6 { unsigned long long* g_stamp_buffer = nullptr; }
 extern "C" void wkv6_set_debug_buffer(void* p) { wkv6::g_stamp_buffer = reinterpret_cast<unsigned long long*>(p); }
 #endif
 
+namespace wkv6 {
+unsigned long long* g_clock_buffer = nullptr;
+int g_clock_slots = 0;
+namespace { __global__ void pass_marker_kernel() {} }
+}
+
 extern "C" {
 
 const char* wkv6_amd_version(void) { return "0.1"; }
 
+void wkv6_set_clock_buffer(void* buf, int n_slots)
+{
+    wkv6::g_clock_buffer = (buf && n_slots > 0) ? reinterpret_cast<unsigned long long*>(buf) : nullptr;
+    wkv6::g_clock_slots = wkv6::g_clock_buffer ? n_slots : 0;
+}
+int wkv6_pass_marker(void* stream)
+{
+    hipLaunchKernelGGL(wkv6::pass_marker_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    return to_rc(hipGetLastError());
+}
+
 size_t wkv6_backward_workspace_bytes(int B, int T, int C, int H)
 {
-    // scan path: one fp32 [B,T,C] array; chunked path: one fp32 64x64 state per ckpt_tok() tokens and head
+    // scan path: one fp32 [B,T,C] array; chunked path: one fp32 64x64 state per CKPT_TOK tokens and head
     const size_t scan = (size_t)B * T * C * sizeof(float);
     const size_t chunk = chunk_ckpt_floats(B, T, H) * sizeof(float);
     return align_up(scan > chunk ? scan : chunk);
@@ -464,8 +439,6 @@ int wkv6_forward_ckpt_ex(int B, int T, int C, int H, const void* r, const void* 
     a.s_out = s_out;
     a.y = y;
     a.ckpt = reinterpret_cast<float*>(ckpt);
-    tsplit_plan(a, tsplit_segments(a));            // (as chunk_forward will decide)
-    ckpt_note(ckpt, a);
     return to_rc(chunk_forward(a, (hipStream_t)stream));
 }
 
@@ -484,7 +457,6 @@ int wkv6_forward_gn_ex(int B, int T, int C, int H, const void* r, const void* k,
     a.s_out = s_out;
     a.y = y;
     a.ckpt = reinterpret_cast<float*>(ckpt);
-    ckpt_note(ckpt, a);
     a.gn_gate = gate; a.gn_gamma = gamma; a.gn_beta = beta; a.gn_eps = eps; a.gn_out = out; a.gn_stats = stats;
     return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
 }
@@ -526,7 +498,6 @@ int wkv6_forward_rev_ex(int B, int T, int C, int H, const void* r, const void* k
     if (flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN))        // exact scan kernels (fp32 I/O, or forced): same index maps, no checkpoints
         return to_rc(launch_scan_fwd(a, (flags & WKV6_IO_F32) ? IO_F32 : IO_BF16, (hipStream_t)stream));
     a.ckpt = reinterpret_cast<float*>(ckpt);
-    ckpt_note(ckpt, a);
     return to_rc(launch_chunk_fwd(a, (hipStream_t)stream));
 }
 
@@ -571,10 +542,9 @@ static int pair_args(int B, int T, int C, int H, const void* u, const wkv6_seq_s
         a[i].rev_mask = q.rev_n ? q.rev_mask : 0u;
         if (bwd) {
             a[i].gy = q.gy; a[i].gr = q.gr; a[i].gk = q.gk; a[i].gv = q.gv; a[i].gw = q.gw; a[i].gu = q.gu;
-            a[i].ckpt_valid = ckpt_matches(q.ckpt, a[i]) ? 1 : 0;
+            a[i].ckpt_valid = 1;
         } else {
             a[i].y = q.y;
-            ckpt_note(q.ckpt, a[i]);
         }
     }
     return WKV6_OK;
@@ -591,14 +561,6 @@ int wkv6_backward_pair_ex(int B, int T, int C, int H, const void* u, const wkv6_
 {
     ScanArgs a[2];
     if (int rc = pair_args(B, T, C, H, u, s, flags, true, a)) return rc;
-    if (!a[0].ckpt_valid || !a[1].ckpt_valid) {       // checkpoints written under another plan: two self-contained backwards
-        for (int i = 0; i < 2; ++i) {
-            a[i].ckpt_valid = 0;
-            ckpt_note(a[i].ckpt, a[i]);
-            if (hipError_t e = launch_chunk_bwd(a[i], (hipStream_t)stream)) return (int)e;
-        }
-        return WKV6_OK;
-    }
     return to_rc(launch_chunk_bwd_pair(a[0], a[1], (hipStream_t)stream));
 }
 
@@ -628,11 +590,9 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
     a.lens = lens;
     a.zero_tail = 1;                          // y[t > L_b] = 0 (the reference leaves it uninitialised, Q2)
     a.ckpt = keep ? ws.scan[0] : nullptr;
-    ckpt_note(a.ckpt, a);
     if (hipError_t e = run_fwd(a, flags, st)) return (int)e;
     a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0;   // cuda/wkv6_bi_cuda.cu:71-111
     a.ckpt = keep ? ws.scan[1] : nullptr;
-    ckpt_note(a.ckpt, a);
     return to_rc(run_fwd(a, flags, st));
 }
 

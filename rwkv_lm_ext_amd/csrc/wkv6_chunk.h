@@ -89,6 +89,20 @@ __device__ __forceinline__ void halves32(float x, float& lower, float& upper)   
     upper = __uint_as_float(r[1]);
 }
 
+// In-run clock probe (wkv6_set_clock_buffer): hardware wave 0 of a workgroup stamps {s_memtime, s_memrealtime} at its start (which = 0)
+// and its end (which = 1) straight into the buffer -- nothing stays in registers in between.  a.clk == null: one scalar branch.
+__device__ __forceinline__ void clock_stamp(const ScanArgs& a, unsigned slot, int which)
+{
+    if (a.clk && (int)slot < a.clk_slots) {
+        unsigned long long c, r;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r) :: "memory");
+        if ((threadIdx.x & 63) == 0) {
+            a.clk[slot * 4 + 2 * which] = c;
+            a.clk[slot * 4 + 2 * which + 1] = r;
+        }
+    }
+}
+
 __device__ __forceinline__ b8v ld_b8(const char* p) { return *reinterpret_cast<const b8v*>(p); }
 __device__ __forceinline__ b8v ld_b8_2x4(const char* p0, const char* p1)
 {
@@ -111,6 +125,13 @@ __device__ __forceinline__ void split4(const float (&x)[4], uint2& hi, uint2& lo
     const bf2 m10 = __builtin_bit_cast(bf2, c10), m01 = __builtin_bit_cast(bf2, c01);
     hi.x = pack_bf2(x[0], x[1]);
     hi.y = pack_bf2(x[2], x[3]);
+#ifdef WKV6_SPLIT_NODOT
+    // A/B variant (profiles/r05_issue_floor.md): lo = x - float(hi) by unpack (shift / and) + subtract on the plain vector ALU.
+    // v_dot2c_f32_bf16 issues at half rate like the shift, but it shares a pipe with the MFMAs of the SIMD's other waves.
+    lo.x = pack_bf2(x[0] - bf_lo(hi.x), x[1] - bf_hi(hi.x));
+    lo.y = pack_bf2(x[2] - bf_lo(hi.y), x[3] - bf_hi(hi.y));
+    return;
+#endif
     const bf2 h0 = __builtin_bit_cast(bf2, hi.x), h1 = __builtin_bit_cast(bf2, hi.y);
     lo.x = pack_bf2(__builtin_amdgcn_fdot2_f32_bf16(h0, m10, x[0], false), __builtin_amdgcn_fdot2_f32_bf16(h0, m01, x[1], false));
     lo.y = pack_bf2(__builtin_amdgcn_fdot2_f32_bf16(h1, m10, x[2], false), __builtin_amdgcn_fdot2_f32_bf16(h1, m01, x[3], false));

@@ -39,11 +39,11 @@ namespace {
 using namespace chunk;
 
 constexpr int GRP_BYTES = NBLK * BLK_BYTES;
-constexpr int CKX_BYTES = 4 * 4096;         // checkpoint transposition buffers of the four consumers (CKPT_ROW_ORDER)
+constexpr int CKX_BYTES = 4 * 4096;         // checkpoint transposition buffers of the four consumers (row order: wkv6_scan.h)
 
 // STATE_ONLY: no outputs, only the state recurrence (first half of the self-contained backward).
-// With a.ckpt the state is dumped every a.ckpt_tok tokens (fp32, register order:
-// [wave][tile][lane][4]) for the backward kernel.
+// With a.ckpt the state is dumped every CKPT_TOK = 64 tokens (fp32, in the register order of the backward's row waves:
+// wkv6_scan.h) for the backward kernel.
 // ACC: add into y (from a.y_f32 when given) instead of overwriting -- the reverse half of wkv6_bi.
 // GN: the per-head GroupNorm and the gate multiply behind the operator (src/model.py:462-468) happen in the
 // store epilogue: a token's statistics span the head's 64 channels = the four consumer waves, which exchange their 16-channel
@@ -51,7 +51,8 @@ constexpr int CKX_BYTES = 4 * 4096;         // checkpoint transposition buffers 
 // GroupNorm_H(y) * gate one group later from the y they kept in registers; y makes no round trip through HBM.
 // The kernel proper is a device function of (arguments, workgroup slot): chunk_fwd_kernel runs it on its one argument block,
 // chunk_fwd_pair_kernel (the two WKV problems of a bidirectional composition in ONE launch) on one of two.
-template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false>
+// CLK: the in-run clock probe (wkv6_set_clock_buffer) is compiled into the plain kernel only.
+template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false, bool CLK = false>
 __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2] | float [4 consumers][1024]
@@ -82,6 +83,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
     unsigned long long clk0 = 0, rtc0 = 0, clk1 = 0, rtc1 = 0;
     WKV6_CLK(clk0, rtc0);
 #endif
+    if constexpr (CLK) { if (hwid == 0) clock_stamp(a, slot, 0); }
 
     if (producer) {
         // ================================ producer: operands of block wv =================================
@@ -270,10 +272,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
         // (a null y -- the fused-epilogue forward of an inference call -- gets a zero-sized resource: its stores are dropped)
         const rsrc_t rs_y = make_rsrc(a.y ? gy_ : nullptr, (!STATE_ONLY && a.y && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
-        // checkpoint spacing: 32 or 64 tokens, a power of two -- shifts and masks below, not the 25-instruction scalar division
-        // sequences a run-time divisor costs the consumers in every block (worth 0-0.5 %: profiles/r04_fwd_ab.txt)
-        const unsigned ckt = (unsigned)a.ckpt_tok, cksh = (unsigned)__builtin_ctz(ckt | 1024u);
-        const unsigned nst = ((unsigned)a.T + ckt - 1) >> cksh;                  // checkpoint slots of this (batch, head): 16 KB each
+        const unsigned nst = ((unsigned)a.T + CKPT_TOK - 1) / CKPT_TOK;         // checkpoint slots of this (batch, head): 16 KB each
         // (two-level scan: this batch row is segment b % S of sequence b / S; the S segments' slots are consecutive, which is the
         // whole sequence's ordinary checkpoint layout)
         const int segs = a.ckpt_segs > 1 ? a.ckpt_segs : 1;
@@ -373,39 +372,27 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 typedef unsigned v4u __attribute__((ext_vector_type(4)));
                 v4u ckd[4];
                 int ck_off = -1;                                  // >= 0: a row-order checkpoint waits in ckd for its stores
-                if (a.ckpt && ((unsigned)(blk * BLK) & (ckt - 1)) == 0) {   // state every ckpt_tok tokens, for the backward kernel (slots past T: dropped)
-                    const unsigned st = (unsigned)(grp * GRP + blk * BLK) >> cksh;
-                    if (a.ckpt_fmt == CKPT_ROW_ORDER) {
-                        // The backward's row waves want key row i on the lane and four consecutive value columns per register quad;
-                        // here a lane holds one value column j and four consecutive key rows per quad.  The 64 x 16 slice of this
-                        // wave goes through 4 KB of LDS: 16 scalar writes, 4 float4 reads, both conflict-free with the float index
-                        //     jl0 | jl1 | jl2^i0 | jl3^i1 | i3 | i2 | i0 | i1 | i4 | i5        (i = key row, jl = j - 16 wv)
-                        // (the 32 lanes of a write group differ in jl and i3, the 16 lanes of a float4 read group in i0..i3 with
-                        // jl3 = i2 ^ i3 ^ const: both land on distinct banks), then leaves as four coalesced 16-byte stores -- per
-                        // (row wave, column tile, g) 16 lanes cover 256 contiguous bytes of the backward's register image.  The reads are
-                        // issued here, the stores at the end of the block: their LDS latency runs under the block's MFMAs.
-#ifdef WKV6_EXP_CK_NOLDS                                         // timing-only experiment: the row-order store pattern without the LDS transposition (wrong data)
+                if (a.ckpt && blk == 0) {   // state at every group (= CKPT_TOK-token) boundary, for the backward kernel (slots past T: dropped)
+                    const unsigned st = (unsigned)grp;
+                    // The backward's row waves want key row i on the lane and four consecutive value columns per register quad;
+                    // here a lane holds one value column j and four consecutive key rows per quad.  The 64 x 16 slice of this
+                    // wave goes through 4 KB of LDS: 16 scalar writes, 4 float4 reads, both conflict-free with the float index
+                    //     jl0 | jl1 | jl2^i0 | jl3^i1 | i3 | i2 | i0 | i1 | i4 | i5        (i = key row, jl = j - 16 wv)
+                    // (the 32 lanes of a write group differ in jl and i3, the 16 lanes of a float4 read group in i0..i3 with
+                    // jl3 = i2 ^ i3 ^ const: both land on distinct banks), then leaves as four coalesced 16-byte stores -- per
+                    // (row wave, column tile, g) 16 lanes cover 256 contiguous bytes of the backward's register image.  The reads are
+                    // issued here, the stores at the end of the block: their LDS latency runs under the block's MFMAs.
 #pragma unroll
-                        for (int wb = 0; wb < 4; ++wb) ckd[wb] = __builtin_bit_cast(v4u, St[wb]);
-#else
+                    for (int it = 0; it < 4; ++it)
 #pragma unroll
-                        for (int it = 0; it < 4; ++it)
+                        for (int q = 0; q < 4; ++q)     // S[i = tile_ch(it) + 8g + q][jl = x]
+                            *reinterpret_cast<float*>(ckx + ((x ^ (q << 2)) + 16 * (g & 1) + 256 * (g >> 1) + 64 * (q & 1) + 128 * (q >> 1)
+                                                             + 32 * (it & 1) + 512 * (it >> 1)) * 4) = St[it][q];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)     // S[i = tile_ch(it) + 8g + q][jl = x]
-                                *reinterpret_cast<float*>(ckx + ((x ^ (q << 2)) + 16 * (g & 1) + 256 * (g >> 1) + 64 * (q & 1) + 128 * (q >> 1)
-                                                                 + 32 * (it & 1) + 512 * (it >> 1)) * 4) = St[it][q];
-#pragma unroll
-                        for (int wb = 0; wb < 4; ++wb)      // lane (x, g) -> S[i = 16 wb + x][j = 16 wv + 4 (g >> 1) + 8 (g & 1) + 0..3]
-                            ckd[wb] = *reinterpret_cast<const v4u*>(ckx + (4 * ((g >> 1) ^ (x & 1)) + 8 * ((g & 1) ^ ((x >> 1) & 1)) + 16 * ((x >> 3) & 1)
-                                                                           + 32 * ((x >> 2) & 1) + 64 * (x & 1) + 128 * ((x >> 1) & 1) + 256 * wb) * 4);
-#endif
-                        ck_off = (int)(st * 16384u + (((2 * (wv >> 1) + (g >> 1)) * 64 + 16 * (2 * (wv & 1) + (g & 1)) + x) * 16));
-                    } else {
-#pragma unroll
-                        for (int it = 0; it < 4; ++it)   // streamed: written once, read once by the backward
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, St[it]), rs_ck,
-                                                                   (int)(((st * 16u + wv * 4u + it) * 64u + lane) * 16u), 0, 2 /* slc: streaming */);
-                    }
+                    for (int wb = 0; wb < 4; ++wb)      // lane (x, g) -> S[i = 16 wb + x][j = 16 wv + 4 (g >> 1) + 8 (g & 1) + 0..3]
+                        ckd[wb] = *reinterpret_cast<const v4u*>(ckx + (4 * ((g >> 1) ^ (x & 1)) + 8 * ((g & 1) ^ ((x >> 1) & 1)) + 16 * ((x >> 3) & 1)
+                                                                       + 32 * ((x >> 2) & 1) + 64 * (x & 1) + 128 * ((x >> 1) & 1) + 256 * wb) * 4);
+                    ck_off = (int)(st * 16384u + (((2 * (wv >> 1) + (g >> 1)) * 64 + 16 * (2 * (wv & 1) + (g & 1)) + x) * 16));
                 }
                 // value fragment: lane holds V[4g + e][16wv + x], e = 0..3  (A operand of (2), B operand of (4))
                 // ALL of the block's LDS operands are requested here, in one go, and the scheduler may not sink them: left to itself hipcc
@@ -541,6 +528,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         d[7] = rtc1 - rtc0;
     }
 #endif
+    if constexpr (CLK) { if (hwid == 0) clock_stamp(a, slot, 1); }
     if (!STATE_ONLY && !ACC && a.zero_tail) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); part == 0 && t < a.T; t += (int)(blockDim.x >> 4))
@@ -551,7 +539,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false>
 __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 {
-    chunk_fwd_body<W_RAW, STATE_ONLY, ACC, GN>(a, blockIdx.x);
+    chunk_fwd_body<W_RAW, STATE_ONLY, ACC, GN, !STATE_ONLY && !ACC && !GN>(a, blockIdx.x);
 }
 
 // Two problems of the same shape in one grid of 2 B H workgroups: slots [0, B H) serve a0, the rest a1 (src/model_bi.py:331-348,
@@ -586,6 +574,7 @@ hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
     if (!offsets_fit(a_)) return hipErrorInvalidValue;
     ScanArgs a = a_;
     a.split = want_split(a.B * a.H);
+    a.clk = g_clock_buffer; a.clk_slots = g_clock_slots;
 #ifdef WKV6_DEBUGBUF
     a.aux = reinterpret_cast<float*>(g_stamp_buffer);
 #endif
@@ -635,8 +624,7 @@ hipError_t launch_chunk_state_pass(const ScanArgs& a_, hipStream_t st)
 
 size_t chunk_ckpt_floats(int B, int T, int H)
 {
-    const int ckt = chunk_ckpt_plan(B * H).tok;
-    return (size_t)B * H * ((T + ckt - 1) / ckt) * HEAD * HEAD;
+    return (size_t)B * H * ((T + CKPT_TOK - 1) / CKPT_TOK) * HEAD * HEAD;
 }
 
 }  // namespace wkv6

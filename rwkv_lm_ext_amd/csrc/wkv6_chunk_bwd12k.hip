@@ -16,7 +16,7 @@
 //
 // The forward states are needed in reverse order.  The forward kernel (or, for a self-contained backward, its state-only variant,
 // launch_chunk_state_pass) dumps the state at every 64-token boundary (fp32, 4 B per token-channel) in the register order of this
-// kernel's row waves (CKPT_ROW_ORDER, wkv6_scan.h); this kernel walks 32-token stages backwards, takes the checkpoint of the
+// kernel's row waves (wkv6_scan.h: CKPT_TOK); this kernel walks 32-token stages backwards, takes the checkpoint of the
 // enclosing 64-token pair straight into registers (four coalesced 16-byte loads per lane, requested a stage's chain ahead) and
 // rebuilds what lies between: one block state inside every stage as before, and on the ODD stage of a pair the two block states
 // of the even stage in front of it.  That rebuild needs Khat, V and the block decays of stage s-1 while stage s is consumed, one
@@ -64,7 +64,7 @@ constexpr int RBUF_BYTES = SBLK * RBLK_BYTES;                          // R part
 constexpr int KBUF_BYTES = SBLK * KBLK_BYTES;                          // K part of one stage; ring of three
 constexpr int KRING = 3;
 constexpr int KP_OFF = 2 * RBUF_BYTES;
-constexpr int CKT = 64;                                                // tokens between checkpoints
+constexpr int CKT = CKPT_TOK;                                          // tokens between checkpoints (wkv6_scan.h)
 // Tiles that every row wave (dA, both orientations, per block) and every column wave (masked scores per block) needs are computed
 // ONCE per workgroup and handed over as MFMA fragments: row waves 2 and 3 make the dA tiles of blocks 0 and 1 (both orientations), row
 // waves 0 and 1 the score tiles of blocks 0 and 1.  The waves of a role are not synchronised inside a stage, so each tile carries a tag
@@ -119,7 +119,9 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 // roles cannot share LDS there: G is kept in both orientations (by rows in the row workgroup for gk, by columns in the column
 // workgroup for gv: no published operand), the producers copy v and gy themselves, and the column waves make their own score
 // tiles.  Every wave does the same arithmetic as in the one-workgroup launch: the outputs are bit-identical.
-template <bool W_RAW, int GEN, bool SPLIT>
+// CLK: the in-run clock probe (wkv6_set_clock_buffer) is compiled into the plain kernel only (it costs ~6 SGPRs, which the wkv6_bi
+// and pair instantiations do not have).
+template <bool W_RAW, int GEN, bool SPLIT, bool CLK = false>
 __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][RBLK_BYTES] | [3][SBLK][KBLK_BYTES] | tiles | G operand
@@ -145,11 +147,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const RevMap tokmap = make_revmap(a, b, ntok);
     // buffer resources over this row's first ntok tokens (wkv6_common.h): loads past the end return 0, stores are dropped
-#ifdef WKV6_EXP_NOSTORE                                               // timing-only experiment: every gradient store dropped by the bounds check
-    const unsigned nbytes = 0u;
-#else
     const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
-#endif
     const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);
     // wkv6_bi's halves: the first (GEN == 1) writes its four gradients into fp32 side buffers (always there: checked at launch), the
     // second (GEN == 2) requests them ahead of the work whose result they meet, adds and rounds once.  Side buffers and outputs alike
@@ -230,6 +228,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     unsigned long long clk0 = 0, rtc0 = 0, clk1 = 0, rtc1 = 0;
     WKV6_CLK(clk0, rtc0);
 #endif
+    if constexpr (CLK) { if (hwid == 0) clock_stamp(a, slot, 0); }
     const int ngrp = (ntok + STG - 1) / STG;                      // stages
     // images of stage s: R part in buffer s & 1, K part in ring slot s mod 3
     auto rpart = [&](int stg, int blk) { return smem + (stg & 1) * RBUF_BYTES + blk * RBLK_BYTES; };
@@ -240,6 +239,9 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     const int ch0 = 32 * half + 4 * c8i;
     float uu[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + ch0, uu);
+    // (every role loads it: moving the load into the producer branch removes the one two-register spill of the GEN = 1 unsplit
+    // instantiation -- a store in front of the row waves' loop and a reload behind it, nothing inside -- but sends the register
+    // allocation of the default instantiation from 150 to 167 VGPRs; tests/test_isa_cpu.py keeps scratch accesses out of every loop)
 
     // register sets: n* = loads in flight (r of stage s-2; k, w of stage s-3), p* = the sets being worked on, c* = what a stage's K part
     // hands to its R part one iteration later (raw k, exponents of fR, the gw multipliers, c_8)
@@ -589,7 +591,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         float Rc[4] = {0.f, 0.f, 0.f, 0.f}, gu_acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.rc_in) io4<float>::load(a.rc_in + (long)b * a.C + h * HEAD + 16 * wv + 4 * g, Rc);   // the suffix sum beyond this segment
         // Checkpoint of the 64-token pair that holds stage `stg`: the forward wrote it in this wave's register order
-        // ([row wave][jt][lane][4], wkv6_scan.h: CKPT_ROW_ORDER), so the slice is four coalesced 16-byte loads per lane straight into
+        // ([row wave][jt][lane][4], wkv6_scan.h), so the slice is four coalesced 16-byte loads per lane straight into
         // registers.  Requested behind a stage's pre-phase (the registers of the stage's own states are dead by then) for the NEXT
         // stage: the latency runs under the chain, the barrier and the next stage's tile work.  Both stages of a pair read the
         // same checkpoint; the second read comes from the L2.
@@ -1223,6 +1225,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         d[7] = rtc1 - rtc0;
     }
 #endif
+    if constexpr (CLK) { if (hwid == 0) clock_stamp(a, slot, 1); }
     if (GEN == 1 && a.zero_tail && part == 0) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = ntok + (tid >> 4); t < a.T; t += (int)(blockDim.x >> 4)) {
@@ -1238,7 +1241,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 template <bool W_RAW, int GEN, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 512 : 768) void chunk_bwd12k_kernel(const ScanArgs a)
 {
-    chunk_bwd12k_body<W_RAW, GEN, SPLIT>(a, blockIdx.x);
+    chunk_bwd12k_body<W_RAW, GEN, SPLIT, GEN == 0>(a, blockIdx.x);
 }
 
 // the backward of chunk_fwd_pair_kernel (wkv6_chunk.hip): two problems of one shape, slots [0, B H) serve a0, the rest a1
@@ -1295,30 +1298,15 @@ int want_split(int BH)
     return 2 * BH <= cu_count();
 }
 
-// Which chunked backward serves a call, hence how far apart the forward's checkpoints are and how one is laid out (wkv6_scan.h).
-// Default: this file's kernel over 64-token checkpoints in row-wave order, with one or two workgroups per (batch, head).  The one
-// switch left, read per call (a backward that is told its checkpoints are valid checks what the forward noted for that buffer:
-// wkv6_api.hip, ckpt_note): WKV6_BWD=64 -- the two-level 16-wave experiment wkv6_chunk_bwd64.hip (64-token checkpoints in forward
-// order, one workgroup per pair only; profiles/r03_bwd64_*).  (Round 3's 32-token kernel, wkv6_chunk_bwd12.hip, was retired in
-// round 4 once this kernel had taken over its two-workgroup mode: profiles/r04_ck64_*, r04_split_mode_ab.txt have the A/B numbers.)
-CkptPlan chunk_ckpt_plan(int BH)
-{
-    if (const char* e = getenv("WKV6_BWD")) {
-        if (atoi(e) == 64 && !want_split(BH)) return CkptPlan{64, CKPT_FWD_ORDER};
-    }
-    return CkptPlan{CKT, CKPT_ROW_ORDER};
-}
-
 // reverse pass over 64-token row-order checkpoints (a.ckpt filled by the forward or by launch_chunk_state_pass); a.split as given
 hipError_t launch_chunk_bwd12k(const ScanArgs& a_, hipStream_t st)
 {
-    if (a_.ckpt_tok != CKT || a_.ckpt_fmt != CKPT_ROW_ORDER || !a_.ckpt) return hipErrorInvalidValue;
+    if (!a_.ckpt) return hipErrorInvalidValue;
     if (a_.split && (a_.g_in || a_.rc_in)) return hipErrorInvalidValue;     // (segment rows of a two-level scan run one workgroup each)
-#ifdef WKV6_DEBUGBUF
     ScanArgs a = a_;
+    a.clk = g_clock_buffer ? g_clock_buffer + (size_t)g_clock_slots * 4 : nullptr; a.clk_slots = g_clock_slots;
+#ifdef WKV6_DEBUGBUF
     a.aux = reinterpret_cast<float*>(g_stamp_buffer);
-#else
-    const ScanArgs& a = a_;
 #endif
     return a.wkind ? launch_bwd12k_variant<true>(a, st) : launch_bwd12k_variant<false>(a, st);
 }
@@ -1326,16 +1314,14 @@ hipError_t launch_chunk_bwd12k(const ScanArgs& a_, hipStream_t st)
 hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)
 {
     ScanArgs a = a_;
-    if (a.ckpt_tok != 64) return hipErrorInvalidValue;
-    a.split = a.ckpt_fmt == CKPT_ROW_ORDER ? want_split(a.B * a.H) : 0;
+    a.split = want_split(a.B * a.H);
     if (a.wkind != 1 && ((long)a.T + 64) * a.C >= (1L << 30)) return hipErrorInvalidValue;   // 32-bit byte offsets of the fp32 decay input
     if (!a.ckpt_valid) {                   // self-contained backward: state pass first (same inputs, no outputs)
         ScanArgs sp = a;
         sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
         if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
     }
-    if (a.ckpt_fmt == CKPT_ROW_ORDER) return launch_chunk_bwd12k(a, st);
-    return launch_chunk_bwd64(a, st);
+    return launch_chunk_bwd12k(a, st);
 }
 
 // Backward of both problems of a bidirectional composition in one launch; both checkpoint sets must come from the forward
@@ -1347,8 +1333,7 @@ hipError_t launch_chunk_bwd_pair(const ScanArgs& a0_, const ScanArgs& a1_, hipSt
         return !a.accumulate && !a.zero_tail && !a.g_f32[0] && !a.g_f32[1] && !a.g_f32[2] && !a.g_f32[3] && a.ckpt && a.ckpt_valid;
     };
     if (!plain(a0_) || !plain(a1_)) return hipErrorNotSupported;
-    const bool rowfmt = a0_.ckpt_fmt == CKPT_ROW_ORDER && a1_.ckpt_fmt == CKPT_ROW_ORDER && a0_.ckpt_tok == CKT && a1_.ckpt_tok == CKT;
-    if (!rowfmt || want_split(a0_.B * a0_.H)) {
+    if (want_split(a0_.B * a0_.H)) {
         if (hipError_t e = launch_chunk_bwd(a0_, st)) return e;
         return launch_chunk_bwd(a1_, st);
     }

@@ -23,17 +23,12 @@
 
 namespace wkv6 {
 
-// The chunked forward leaves fp32 state checkpoints for the chunked backward, one 64x64 state per 64 tokens and head (4 B per
-// token-channel); which backward kernel serves a call decides how one is laid out:
-//   * default: wkv6_chunk_bwd12k.hip -- in the register order of that kernel's row waves (CKPT_ROW_ORDER: [row wave i>>4][column tile jt]
-//     [lane 16 g + (i & 15)][4 columns tile_ch(jt) + 8 g + q]), so that a row wave takes its 16x64 slice with four coalesced 16-byte
-//     loads; with one or two workgroups per (batch, head);
-//   * WKV6_BWD=64: the two-level experiment wkv6_chunk_bwd64.hip -- in the forward consumers' register order (CKPT_FWD_ORDER:
-//     [consumer wave j>>4][tile it][lane][4 key rows]).
-enum { CKPT_FWD_ORDER = 0, CKPT_ROW_ORDER = 1 };
-struct CkptPlan { int tok, fmt; };
-CkptPlan chunk_ckpt_plan(int BH);            // wkv6_chunk_bwd12k.hip
-inline int chunk_ckpt_tok(int BH) { return chunk_ckpt_plan(BH).tok; }
+// The chunked forward leaves fp32 state checkpoints for the chunked backward (wkv6_chunk_bwd12k.hip, one or two workgroups per
+// (batch, head)): one 64x64 state per CKPT_TOK = 64 tokens and head (4 B per token-channel), laid out in the register order of
+// that kernel's row waves -- [row wave i>>4][column tile jt][lane 16 g + (i & 15)][4 columns tile_ch(jt) + 8 g + q] -- so that a row
+// wave takes its 16x64 slice with four coalesced 16-byte loads.  (Rounds 3-4 had a second, opt-in layout for the two-level backward
+// experiment, now parked under tools/experiments/.)
+constexpr int CKPT_TOK = 64;
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute is per device.
 struct LdsAttrOnce {
@@ -69,9 +64,7 @@ struct ScanArgs {
     void* gs;                         // [B,H,N,N] per-batch dL/dS0, I/O type (null: skip)
     int part_f32;                     // gu and gs are fp32 whatever the I/O type (WKV6_PARTIALS_F32): the caller sums them over the batch
     float* aux;                       // [B,T,C] fp32 scratch carrying a_t from sweep S to sweep G
-    float* ckpt;                      // chunked path: [B*H][ceil(T/32)][4096] fp32 stage-entry states (forward / state pass -> backward)
-    int ckpt_tok;                     // tokens between checkpoints: chunk_ckpt_plan(B*H).tok
-    int ckpt_fmt;                     // layout of one checkpoint: CKPT_FWD_ORDER / CKPT_ROW_ORDER (chunk_ckpt_plan(B*H).fmt)
+    float* ckpt;                      // chunked path: [B*H][ceil(T/CKPT_TOK)][4096] fp32 states at 64-token boundaries (forward / state pass -> backward)
     int ckpt_valid;                   // backward: ckpt was filled by the forward, skip the state pass
     const int* lens;                  // per-batch number of tokens to scan (null: T)
     const int* order;                 // chunked kernels: batch row served by workgroup slot blockIdx / H (null: identity) -- rows
@@ -96,6 +89,8 @@ struct ScanArgs {
                                       // entering this row (= segment) from the future, or null (zero)
     const float* rc_in;               // ... and fp32 [B,C]: the gw suffix sum at the segment's end, sum_{s >= end} (a_s - b_s) =
                                       // Phi[i] = sum_j G[i][j] S[i][j] at the boundary, or null (zero)
+    unsigned long long* clk;          // chunked kernels: clock stamps of wave 0 of workgroup slots < clk_slots ({memtime, memrealtime} at start
+    int clk_slots;                    //   and end: wkv6_set_clock_buffer, include/wkv6_amd.h), or null (the default: no stamp executes)
     int split;                        // chunked kernels, set by the launcher when B*H leaves half the chip idle: two workgroups per
                                       // (batch, head), each with its own producers and half of the consuming waves
 };
@@ -126,10 +121,11 @@ hipError_t launch_chunk_fwd_pair(const ScanArgs& a0, const ScanArgs& a1, hipStre
 hipError_t launch_chunk_bwd_pair(const ScanArgs& a0, const ScanArgs& a1, hipStream_t st);
 // chunked MFMA backward (bf16 I/O only): state pass + reverse pass; a.ckpt must hold chunk_ckpt_floats() floats
 hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st);
-hipError_t launch_chunk_bwd64(const ScanArgs& a, hipStream_t st);     // two-level backward proper (wkv6_chunk_bwd64.hip)
 hipError_t launch_chunk_bwd12k(const ScanArgs& a, hipStream_t st);    // reverse pass over 64-token row-order checkpoints, a.split as given (wkv6_chunk_bwd12k.hip)
 size_t chunk_ckpt_floats(int B, int T, int H);
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // state recurrence only (s_out, ckpt, dsum)
+extern unsigned long long* g_clock_buffer;   // wkv6_set_clock_buffer (wkv6_api.hip)
+extern int g_clock_slots;
 int cu_count();
 int want_split(int BH);                      // two workgroups per (batch, head)?  (wkv6_chunk_bwd12k.hip)
 

@@ -47,7 +47,10 @@ class LoraLinear(nn.Module):
         return m
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.bfloat16 and self.lora_dropout.p == 0.0 and self.weight.dtype == torch.bfloat16:
+        # fused path: bf16 everywhere, no dropout, and a FROZEN base weight (the reference's trainer freezes it; a caller that trains
+        # it gets the eager path, whose autograd produces the weight gradient the fused backward does not)
+        if (x.is_cuda and self.lora_dropout.p == 0.0 and not self.weight.requires_grad
+                and x.dtype == self.weight.dtype == self.lora_A.dtype == self.lora_B.dtype == torch.bfloat16):
             return _LoraLinearFn.apply(x, self.weight, self.lora_A, self.lora_B, self.scaling)
         return F.linear(x, self.weight) + self.scaling * F.linear(F.linear(self.lora_dropout(x), self.lora_A), self.lora_B)
 

@@ -484,6 +484,35 @@ def selftest():
     return _lib.load().wkv6_selftest(_stream_ptr())
 
 
+def pass_marker():
+    """Launch the empty kernel wkv6::pass_marker_kernel on the current stream (a phase boundary in a profiler's dispatch list)."""
+    _lib.check(_lib.load().wkv6_pass_marker(_stream_ptr()), "wkv6_pass_marker")
+
+
+class ClockProbe:
+    """In-run shader clock of the chunked kernels (wkv6_set_clock_buffer, include/wkv6_amd.h): while active, wave 0 of the first
+    `n_slots` workgroups of every chunked forward / backward launch stamps {s_memtime, s_memrealtime} at its start and end.
+    read() -> {"fwd_ghz", "bwd_ghz"}: median over the workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz for the LAST launch of
+    each kernel (None where nothing was stamped)."""
+
+    def __init__(self, device, n_slots=256):
+        self.n = n_slots
+        self.buf = torch.zeros(2 * n_slots * 4, dtype=torch.int64, device=device)
+        _lib.load().wkv6_set_clock_buffer(self.buf.data_ptr(), n_slots)
+
+    def read(self):
+        d = self.buf.view(2, self.n, 4).cpu().double()
+        out = {}
+        for i, name in enumerate(("fwd_ghz", "bwd_ghz")):
+            dc, dr = d[i, :, 2] - d[i, :, 0], d[i, :, 3] - d[i, :, 1]
+            ok = (dr > 0) & (d[i, :, 0] > 0)
+            out[name] = round(float((dc[ok] / dr[ok]).median()) * 0.1, 3) if bool(ok.any()) else None
+        return out
+
+    def close(self):
+        _lib.load().wkv6_set_clock_buffer(None, 0)
+
+
 # ---- torch.ops registration: the TORCH_LIBRARY(wkv6|wkv6bi|wkv6state|wkv6infctx, m) blocks ------------
 def _register():
     T9 = "Tensor r, Tensor k, Tensor v, Tensor w, Tensor u"

@@ -23,8 +23,8 @@ def test_committed_pmc_figures_are_consistent():
     assert abs(bwd - (units * 18 + ckpt)) <= 0.02 * bwd
     assert abs(fwd - (units * 10 + ckpt)) <= 0.02 * fwd
     for k in ("chunk_bwd12k_kernel", "chunk_fwd_kernel"):
-        assert 0.2 < bench.valu_busy_of(pmc[k]["counters"]) < 1.0
-    assert bench.valu_busy_of({}) is None
+        assert 0.2 < bench.valu_issue_share_of(pmc[k]["counters"]) < 1.0
+    assert bench.valu_issue_share_of({}) is None
 
 
 def test_committed_bench_lines_carry_the_contract_fields():
@@ -41,20 +41,33 @@ def test_committed_bench_lines_carry_the_contract_fields():
 
 
 def test_live_counter_rows_reduce_to_per_launch_hbm_bytes():
-    """bench.pmc_live's parsing: several rows per (dispatch, counter) are summed, launches averaged, FETCH_SIZE doubled (gfx950)."""
+    """bench.pmc_live's parsing: several rows per (dispatch, counter) are summed, launches averaged, FETCH_SIZE doubled (gfx950);
+    whole-pass totals are attributed by the phase markers the profiled child launches (marker, forwards, marker, backwards, marker),
+    not by kernel names: a backward's own state pass carries a forward kernel's name."""
     rows = []
-    kn = "void wkv6::(anonymous namespace)::chunk_bwd12_kernel<true, 0>(wkv6::ScanArgs)"
-    for disp in ("1", "2"):
-        for inst in range(8):                                    # one row per XCD
-            rows.append({"Kernel_Name": kn, "Counter_Name": "FETCH_SIZE", "Dispatch_Id": disp, "Counter_Value": "100.0"})
-            rows.append({"Kernel_Name": kn, "Counter_Name": "WRITE_SIZE", "Dispatch_Id": disp, "Counter_Value": "50.0"})
-    rows.append({"Kernel_Name": "some_torch_kernel", "Counter_Name": "FETCH_SIZE", "Dispatch_Id": "3", "Counter_Value": "9e9"})
+    kn = "void wkv6::(anonymous namespace)::chunk_bwd12k_kernel<true, 0, false>(wkv6::ScanArgs)"
+    fw = "void wkv6::(anonymous namespace)::chunk_fwd_kernel<true, true, false, false>(wkv6::ScanArgs)"     # a state pass
+    mk = "wkv6::(anonymous namespace)::pass_marker_kernel()"
+
+    def add(name, disp, fetch, write, n=8):
+        for _ in range(n):                                       # one row per XCD
+            rows.append({"Kernel_Name": name, "Counter_Name": "FETCH_SIZE", "Dispatch_Id": str(disp), "Counter_Value": str(fetch)})
+            rows.append({"Kernel_Name": name, "Counter_Name": "WRITE_SIZE", "Dispatch_Id": str(disp), "Counter_Value": str(write)})
+    add(fw, 1, 7.0, 7.0)                                          # in front of the first marker: belongs to no pass
+    add(mk, 2, 0.0, 0.0, n=1)
+    add(fw, 3, 10.0, 20.0)                                        # forward pass
+    add(mk, 4, 0.0, 0.0, n=1)
+    add(fw, 5, 1.0, 2.0)                                          # the backward's state pass: backward traffic
+    add(kn, 6, 100.0, 50.0)
+    add(kn, 7, 100.0, 50.0)
+    add(mk, 8, 0.0, 0.0, n=1)
+    rows.append({"Kernel_Name": "some_torch_kernel", "Counter_Name": "FETCH_SIZE", "Dispatch_Id": "9", "Counter_Value": "9e9"})
     acc = {}
     bench.add_counter_rows(iter(rows), acc)          # a one-shot iterator, as csv.DictReader is
     out = bench.reduce_counters(acc)
-    assert sorted(out) == ["_pass_bwd", "chunk_bwd12_kernel"]
-    assert out["chunk_bwd12_kernel"]["counters"] == {"FETCH_SIZE": 800.0, "WRITE_SIZE": 400.0}
-    assert out["chunk_bwd12_kernel"]["hbm_bytes"] == (2 * 800 + 400) * 1024
-    # whole-pass totals (workloads of several launches per pass): every dispatch of the library's kernels, per child step
-    assert out["_pass_bwd"]["counters"] == {"FETCH_SIZE": 1600.0 / bench.PMC_CHILD_STEPS, "WRITE_SIZE": 800.0 / bench.PMC_CHILD_STEPS}
-
+    assert sorted(out) == ["_pass_bwd", "_pass_fwd", "chunk_bwd12k_kernel", "chunk_fwd_kernel"]
+    assert out["chunk_bwd12k_kernel"]["counters"] == {"FETCH_SIZE": 800.0, "WRITE_SIZE": 400.0}
+    assert out["chunk_bwd12k_kernel"]["hbm_bytes"] == (2 * 800 + 400) * 1024
+    n = bench.PMC_CHILD_STEPS
+    assert out["_pass_fwd"]["counters"] == {"FETCH_SIZE": 80.0 / n, "WRITE_SIZE": 160.0 / n}
+    assert out["_pass_bwd"]["counters"] == {"FETCH_SIZE": (8.0 + 1600.0) / n, "WRITE_SIZE": (16.0 + 800.0) / n}

@@ -1,12 +1,10 @@
-"""GPU parity of the backward kernels in their ONE-workgroup-per-(batch, head) mode, forced onto every shape of the suite:
-  * `12k` -- csrc/wkv6_chunk_bwd12k.hip, the default backward (64-token row-order checkpoints, K part of the stage image two stages
-    ahead); the suite's small shapes would otherwise run its two-workgroups-per-pair mode, so WKV6_SPLIT=0 puts them on the
-    mode the benched shapes use (the split mode is what the rest of the suite exercises, and both are bit-identical:
-    test_wkv6_gpu.py::test_two_workgroups_per_head_is_the_same_arithmetic);
-  * `64`  -- csrc/wkv6_chunk_bwd64.hip, the two-level experiment behind WKV6_BWD=64 (integer reference frames);
-at the same bf16 contract as everything else: golden vectors generated from the reference, the oracle on random shapes, the exact
-scan kernels at every block / stage / checkpoint boundary, the wkv6_bi and in-kernel-reversal store paths, and config 2 at full
-size against oracle slices and the exact scan kernels."""
+"""GPU parity of the backward kernel (csrc/wkv6_chunk_bwd12k.hip: 64-token row-order checkpoints, K part of the stage image two
+stages ahead) in its ONE-workgroup-per-(batch, head) mode, forced onto every shape of the suite: the suite's small shapes would
+otherwise run its two-workgroups-per-pair mode, so WKV6_SPLIT=0 puts them on the mode the benched shapes use (the split mode is
+what the rest of the suite exercises, and both are bit-identical: test_wkv6_gpu.py::test_two_workgroups_per_head_is_the_same_arithmetic).
+Same bf16 contract as everything else: golden vectors generated from the reference, the oracle on random shapes, the exact scan
+kernels at every block / stage / checkpoint boundary, the wkv6_bi and in-kernel-reversal store paths, rows of 0 .. 65 tokens beside
+long ones in one launch (the hand-over protocol at its edges), and config 2 at full size against oracle slices and the scan kernels."""
 import numpy as np
 import pytest
 import torch
@@ -26,19 +24,11 @@ def ops():
     return wkv6_op
 
 
-@pytest.fixture(params=["12k", "64"])
-def two_level(monkeypatch, request):
-    """Select one of the 64-token-checkpoint backward kernels for every shape (the library reads the switches at each call); the
-    forward then leaves its checkpoints 64 tokens apart.  WKV6_SPLIT=0: small (batch, head) counts would otherwise run two
-    workgroups per pair (which the two-level experiment cannot do).  Returns a function that re-selects the kernel."""
-    def select():
-        if request.param == "64":
-            monkeypatch.setenv("WKV6_BWD", "64")
-        else:
-            monkeypatch.delenv("WKV6_BWD", raising=False)
-        monkeypatch.setenv("WKV6_SPLIT", "0")
-    select()
-    return select
+@pytest.fixture
+def two_level(monkeypatch):
+    """One workgroup per (batch, head) for every shape (the library reads the switch at each call): small (batch, head) counts would
+    otherwise run two workgroups per pair."""
+    monkeypatch.setenv("WKV6_SPLIT", "0")
 
 
 @pytest.mark.parametrize("name", ["wkv6_init", "wkv6_stress", "wkv6_extreme", "wkv6_T1", "wkv6_T2", "wkv6_T3", "wkv6_state", "wkv6_infctx"])
@@ -207,3 +197,43 @@ def test_config2_full_size_vs_oracle_slices_and_scan(ops, oracle, two_level, mon
         worst = float((np.abs(a - b_)[big] / np.abs(b_[big])).max())
         # (gw: each kernel is within two bf16 ulps of the oracle on the slices above; between themselves they may be three apart)
         assert same >= (0.9 if n == "gw" else 0.97) and worst <= 2.0 ** -7 * (3.03 if n == "gw" else 2.02), (n, same, worst)
+
+
+def test_ragged_rows_share_one_unsplit_launch(ops, two_level):
+    """Rows of 0, 1, 31, 32, 33, 63, 64, 65 tokens beside long ones in ONE launch with one workgroup per (batch, head): the hand-over
+    protocol of the 12-wave kernel at its edges -- workgroups with no stage at all, with one partial stage, with exactly one / two /
+    three stages next to 7-stage neighbours (every role executes every stage of ITS row: a tag can only be waited for by a wave whose
+    partner is about to write it).  wkv6_bi (first half: forward-direction scan into the fp32 side buffers; second half: reversed
+    scan, accumulating) with the row lengths passed directly, and the in-kernel-reversed operator with the same spans, against the
+    exact scan kernels; forward with kept checkpoints and self-contained backward."""
+    B, T, H = 10, 200, 2
+    lens = torch.tensor([0, 1, 31, 32, 33, 63, 64, 65, 200, 129], dtype=torch.int32, device="cuda")
+    d = [dev(t, BF) for t in rand_inputs(9191, B, T, H, "init")]
+    ws = ops.bi_new_workspace(B, T, H * 64, H, "cuda")
+    y = ops.bi_forward_ex(None, *d[:5], H, ws=ws, lens=lens)
+    ys = ops.bi_forward_ex(None, *d[:5], H, algo="scan", lens=lens)
+    scale = float(np.abs(host(ys)).max())
+    assert float(np.abs(host(y) - host(ys)).max()) <= 2.0 * 2.0 ** -8 * scale
+    for b in range(B):
+        assert np.all(host(y)[b, int(lens[b]):] == 0)
+    ref = ops.bi_backward_ex(None, *d, H, algo="scan", lens=lens)
+    for got in (ops.bi_backward_ex(None, *d, H, ws=ws, lens=lens), ops.bi_backward_ex(None, *d, H, lens=lens)):
+        for n, c, s_ in zip(("gr", "gk", "gv", "gw", "gu"), got, ref):
+            c, s_ = host(c), host(s_)
+            scale = max(float(np.abs(s_).max()), 1e-2 if n == "gw" else 1e-3)
+            assert float(np.abs(c - s_).max()) <= (4.0 if n in ("gw", "gu") else 2.0) * 2.0 ** -8 * scale, n
+            if n != "gu":
+                for b in range(B):
+                    assert np.all(c[b, int(lens[b]):] == 0), (n, b)
+    # the reversed operator: every row is scanned in full, the first rev_n[b] tokens in reverse order
+    for mask in (ops.REV_ALL, ops.REV_K | ops.REV_V | ops.REV_Y):
+        ck = ops.new_checkpoint(B, T, H * 64, H, "cuda")
+        yr = ops.forward_rev_ex(*d[:5], H, lens, mask, ckpt=ck)
+        yrs = ops.forward_rev_ex(*d[:5], H, lens, mask, algo="scan")
+        assert float(np.abs(host(yr) - host(yrs)).max()) <= 2.0 * 2.0 ** -8 * float(np.abs(host(yrs)).max())
+        got = ops.backward_rev_ex(*d, H, lens, mask, ckpt=ck)
+        ref = ops.backward_rev_ex(*d, H, lens, mask, algo="scan")
+        for n, c, s_ in zip(("gr", "gk", "gv", "gw", "gu"), got, ref):
+            c, s_ = host(c), host(s_)
+            scale = max(float(np.abs(s_).max()), 1e-3)
+            assert float(np.abs(c - s_).max()) <= (4.0 if n in ("gw", "gu") else 2.0) * 2.0 ** -8 * scale, (mask, n)

@@ -38,3 +38,37 @@ def test_the_guard_sees_a_drain_when_there_is_one():
     ])
     loops = check_waitcnt.stage_loops(asm, "fooILb1E")
     assert ("BB0_1", 1, 1, [0]) in loops and ("BB0_2", 0, 1, [0]) in loops
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_no_scratch_access_inside_any_loop_and_no_spill_in_the_benched_kernels():
+    """register spills.  From the gfx950 ISA of every instantiation of the chunked kernels: the instantiations the
+    headline benchmark runs (plain stores, one workgroup per (batch, head), both decay kinds) spill no vector register at all, and
+    no instantiation touches scratch memory inside a loop (the one known spill -- two registers of the first wkv6_bi half, stored
+    in front of the row waves' stage loop and reloaded behind it -- is off every loop: wkv6_chunk_bwd12k.hip has the note)."""
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-w", "-S", "--cuda-device-only"]
+    with tempfile.TemporaryDirectory() as tmp:
+        for src in ("wkv6_chunk.hip", "wkv6_chunk_bwd12k.hip"):
+            out = os.path.join(tmp, src + ".s")
+            subprocess.check_call(["hipcc"] + flags + ["-o", out, os.path.join(root, "rwkv_lm_ext_amd", "csrc", src)])
+            asm = open(out).read()
+            spills = dict(zip(re.findall(r"^\s+\.name:\s+(\S+)", asm, re.M), (int(x) for x in re.findall(r"^\s+\.vgpr_spill_count:\s+(\d+)", asm, re.M))))
+            assert spills, src
+            for name, n in spills.items():
+                if "chunk_fwd_kernelILb1ELb0ELb0ELb0E" in name or "chunk_fwd_kernelILb0ELb0ELb0ELb0E" in name or \
+                        "chunk_bwd12k_kernelILb1ELi0ELb0E" in name or "chunk_bwd12k_kernelILb0ELi0ELb0E" in name:
+                    assert n == 0, (name, n)
+            # scratch instructions must sit outside every loop: the asm printer marks loop blocks "in Loop:" / "Loop Header"
+            in_loop = False
+            for line in asm.split("\n"):
+                m = re.match(r"^\.LBB\d+_\d+:\s*(;.*)?$", line)
+                if m:
+                    in_loop = bool(m.group(1)) and ("Loop" in m.group(1))
+                elif re.match(r"^_Z\w+:", line):
+                    in_loop = False
+                elif in_loop and line.strip().startswith("scratch_"):
+                    raise AssertionError(f"{src}: scratch access inside a loop: {line.strip()}")

@@ -60,3 +60,28 @@ def test_lora_training_step_on_the_hip_path_matches_the_bf16_cpu_model():
     for n, p in hip_model.named_parameters():
         assert (not torch.equal(p, before[n])) == p.requires_grad, n        # frozen base untouched, every adapter moved
 
+
+
+def test_ddp_over_rccl_at_world_size_one():
+    """The N > 1 path as far as a one-GPU box can take it: a fresh child process (it has not touched the GPU
+    when it starts; the pytest process is never replaced) initialises `nccl` (= RCCL) at world size 1, wraps the 2-layer LoRA
+    model with train_dp.wrap_ddp and runs one train_steps step with activation checkpointing: DDP's hooks through the custom
+    autograd Functions of the HIP operator, gradient_as_bucket_view and the bucketed all-reduce all execute, and the LoRA / dense
+    gradients equal the un-wrapped step's bit for bit (tests/ddp_child.py)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ddp_child.py")
+    res = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (res.returncode, res.stdout[-2000:], res.stderr[-4000:])
+    out = json.loads(lines[-1])
+    assert res.returncode == 0, (out, res.stderr[-2000:])
+    assert out["backend"] == "nccl" and out["world"] == 1 and out["bitwise_equal"] and out["max_abs_diff"] == 0.0, out

@@ -8,7 +8,7 @@ SRC=rwkv_lm_ext_amd/csrc
 for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     d="$OUT/$name"; mkdir -p "$d"
-    for f in wkv6_scan wkv6_chunk wkv6_chunk_bwd12k wkv6_chunk_bwd64 wkv6_mix wkv6_api; do
+    for f in wkv6_scan wkv6_chunk wkv6_chunk_bwd12k wkv6_mix wkv6_api; do
         hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-strict-aliasing $flags -c $SRC/$f.hip -o "$d/$f.o" &
     done
     wait

@@ -4,7 +4,7 @@
 set -e
 name=$1; flags=$2
 d=build_ab/$name; mkdir -p $d
-for f in wkv6_scan wkv6_chunk wkv6_chunk_bwd12k wkv6_chunk_bwd64 wkv6_mix wkv6_api; do
+for f in wkv6_scan wkv6_chunk wkv6_chunk_bwd12k wkv6_mix wkv6_api; do
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-strict-aliasing $flags -c rwkv_lm_ext_amd/csrc/$f.hip -o $d/$f.o &
 done
 wait
