@@ -40,6 +40,14 @@ using namespace chunk;
 
 constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 constexpr int CKX_BYTES = 4 * 4096;         // checkpoint transposition buffers of the four consumers (row order: wkv6_scan.h)
+// y leaves through LDS as whole token rows.  A consumer's result tile is 16 tokens x 16 channels = 32-byte pieces of the [B, T, C]
+// rows, and stored as such (8 bytes per lane) the forward ran at exactly the speed of its own store shape: the kernel's memory
+// instructions with NO arithmetic take 0.226-0.243 ms at config 2, the same with y as full 128-byte rows at 16 bytes per lane
+// 0.190-0.202 (tools/microbench/head_slices.hip: fwd_shapes, profiles/r05_head_slices_microbench.txt).  So the consumers park a
+// group's y (bf16) in a double-buffered [64 tokens][144 B] image and, behind the group barrier they have anyway, each stores 16
+// whole rows of the group with two 16-byte-per-lane instructions.
+constexpr int YRS = 144;                    // staged y row: 128 B + 16 B pad (16-byte row reads stay aligned; writes are 2-way at most)
+constexpr int YS_BYTES = GRP * YRS;
 
 // STATE_ONLY: no outputs, only the state recurrence (first half of the self-contained backward).
 // With a.ckpt the state is dumped every CKPT_TOK = 64 tokens (fp32, in the register order of the backward's row waves:
@@ -55,7 +63,7 @@ constexpr int CKX_BYTES = 4 * 4096;         // checkpoint transposition buffers 
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false, bool CLK = false>
 __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2] | float [4 consumers][1024]
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2] | float [4 consumers][1024] | y rows [2][64][YRS]
     const int tid = threadIdx.x, lane = tid & 63;
     // a.split (B*H <= half the CUs): two 6-wave workgroups per (batch, head) on two CUs, each with all four producers and two
     // of the four consumers (value columns [32 part, 32 part + 32)): hardware wave w plays consumer 2 part + w for w < 2 and
@@ -99,9 +107,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         const rsrc_t rs_v = make_rsrc(gv_, ntok > 0 ? span * 2 + 128 : 0);
         const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, ntok > 0 ? span * 2 + 128 : 0)
                                   : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? span * 4 + 256 : 0);
-        auto load_group = [&](int grp) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
+        auto load_quad = [&](int grp, int tt) {                       // token quad tt of the wave's block: one instruction per tensor
+            {
                 const int p = grp * GRP + wv * BLK + 4 * tq + tt;
                 const unsigned ir = (unsigned)(tokmap(p, REV_R) * a.C + 4 * c4), ik = (unsigned)(tokmap(p, REV_K) * a.C + 4 * c4);
                 const unsigned iv = (unsigned)(tokmap(p, REV_V) * a.C + 4 * c4), iw = (unsigned)(tokmap(p, REV_W) * a.C + 4 * c4);
@@ -113,13 +120,29 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 else pe[tt] = buf_load16f(rs_w, iw * 4);
             }
         };
+        auto load_group = [&](int grp) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) load_quad(grp, tt);
+        };
         // `next`: group whose loads are requested as soon as the raw registers are consumed, -1: none.  (Requested behind the whole
         // preparation they were in flight only for the barrier wait, ~1000 cycles of every group exposed; on its own the earlier request
         // gained nothing -- the consumers' exposed LDS round trips took the time over -- together with their up-front operand requests
         // 2-3 %: profiles/r04_fwd_prefetch.txt.)
+        // -DWKV6_STAMP -DWKV6_STAMP_PREP: the producers' record holds the cycles of the preparation's phases instead of the loop's:
+        // [unpack / lw / in-lane sums / r.u.k / V copy, next loads' issue, prefix butterfly + block factors, scale + split + stores,
+        //  score tile (LDS round trip, 6 MFMAs, mask, split, store)]
+#if defined(WKV6_STAMP) && defined(WKV6_STAMP_PREP)
+#define WKV6_TP(n) do { unsigned long long t_; WKV6_T(t_); stamp_acc[n] += t_ - tprev; tprev = t_; } while (0)
+        unsigned long long tprev = 0;
+#else
+#define WKV6_TP(n) do { } while (0)
+#endif
         auto prep_group = [&](int grp, int buf, int next) {
             char* const bb = smem + buf * GRP_BYTES + wv * BLK_BYTES;
             float r[4][4], k[4][4], cs[4][4];
+#if defined(WKV6_STAMP) && defined(WKV6_STAMP_PREP)
+            WKV6_T(tprev);
+#endif
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const bool valid = grp * GRP + wv * BLK + 4 * tq + tt < ntok;
@@ -155,7 +178,12 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 }
                 *reinterpret_cast<uint2*>(bb + A_V * ARR + (4 * tq + tt) * RSB + 8 * c4) = pv[tt];
             }
+            WKV6_TP(0);
+            // (the sixteen loads of the next group: ~2000 cycles of issue for the wave wherever they are placed -- behind the whole
+            // preparation, here, or four at a time inside the loop above (+6 %): the four producers' 32 KB per group are a third of
+            // what the CU's vector-memory pipe moves in a group at ~10 B per cycle, profiles/r05_fwd_prep_stamps.txt)
             if (next >= 0) load_group(next);
+            WKV6_TP(1);
             float pre[4], c8[4], c16[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -179,6 +207,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 *reinterpret_cast<float4*>(bb + OFF_E16M8 + 16 * c4) =
                     make_float4(exp2_fast(c16[0] - c8[0]), exp2_fast(c16[1] - c8[1]), exp2_fast(c16[2] - c8[2]), exp2_fast(c16[3] - c8[3]));
             }
+            WKV6_TP(2);
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 float rh[4], kh[4];
@@ -198,6 +227,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 split4(kh, hi, lo);
                 *reinterpret_cast<uint2*>(row + A_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_KL * ARR) = lo;
             }
+            WKV6_TP(3);
             if constexpr (!STATE_ONLY) {
                 // Scores of this block, once for all four consumers: sc[b][a] = sum_i Khat[b][i] Rhat[a][i] from the rows this
                 // wave has just written (LDS operations of one wave execute in order), masked to b < a with the bonus
@@ -225,8 +255,14 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 }
                 uint2 sh, sl;
                 split4(scm, sh, sl);
-                *reinterpret_cast<uint4*>(bb + OFF_SC + lane * 16) = make_uint4(sh.x, sh.y, sl.x, sl.y);
+                // stored [hi | lo][query token a = x][key token b] (32 B per (part, a)): a consumer lane takes the 8 key tokens of one
+                // half of one part with one 16-byte read -- the B fragment of the K-concatenated product (2) below; the two 16-byte
+                // halves of a row swap places for a >= 8 so that rows a and a + 8 (256 B apart) do not share banks in that read
+                char* const scw = bb + OFF_SC + x * 32 + 16 * ((g >> 1) ^ (x >> 3)) + 8 * (g & 1);
+                *reinterpret_cast<uint2*>(scw) = sh;
+                *reinterpret_cast<uint2*>(scw + 512) = sl;
             }
+            WKV6_TP(4);
         };
 
         if (ngrp > 0) {
@@ -248,7 +284,11 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             WKV6_T(ts3);
             __syncthreads();
             WKV6_T(ts4);
+#ifndef WKV6_STAMP_PREP
             WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3);
+#else
+            WKV6_ACC(5, ts4, ts3);                            // (barrier wait)
+#endif
         }
         if (a.dsum && tq == 0 && part == 0)
             *reinterpret_cast<float4*>(a.dsum + ((long)(b * a.H + h) * 4 + wv) * HEAD + 4 * c4) = make_float4(dtot[0], dtot[1], dtot[2], dtot[3]);
@@ -268,8 +308,13 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             St[it] = f4v{t4[0], t4[1], t4[2], t4[3]};
             asm volatile("" : "+v"(St[it]));                       // (an entry state still in flight is waited for here, not inside the loop)
         }
-        int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read, natural columns (this wave's V tile)
-        int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
+        // Token contractions (K = the block's 16 tokens) run as ONE 16x16x32 MFMA per product pair: the hi and lo parts of the split
+        // operand are concatenated along K (k-slots 0..15 = hi of tokens 0..15, 16..31 = lo) against the exact operand repeated
+        // (V | V): lane group g supplies k-slots 8g..8g+7 = tokens 8 (g & 1) .. +7 of part g >> 1.  Both MFMA shapes cost 16 cycles
+        // (profiles/r05_issue_floor.md), so this halves the MFMAs of the state update and of the score product.
+        int troff = (8 * (g & 1) + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read of 4 of those tokens (+ 4 RSB: the other 4), natural columns (this wave's V tile)
+        int trow = (8 * (g & 1) + (x >> 2)) * RSB + 16 * (x & 3) + (g >> 1) * ((A_KL - A_KH) * ARR);   // ... tile-labelled columns (+ tile_tr(t)), Khat hi (g < 2) or lo
+        const int scoff = OFF_SC + 512 * (g >> 1) + 32 * x + 16 * ((g & 1) ^ (x >> 3));               // this lane's 16 bytes of the score fragment
         // (a null y -- the fused-epilogue forward of an inference call -- gets a zero-sized resource: its stores are dropped)
         const rsrc_t rs_y = make_rsrc(a.y ? gy_ : nullptr, (!STATE_ONLY && a.y && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
         const unsigned nst = ((unsigned)a.T + CKPT_TOK - 1) / CKPT_TOK;         // checkpoint slots of this (batch, head): 16 KB each
@@ -317,6 +362,22 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         unsigned gn_off[NBLK];
         char* const gn_stat = smem + 2 * GRP_BYTES;
         char* const ckx = smem + 2 * GRP_BYTES + (GN ? 4096 : 0) + hwid * 4096;   // this consumer's checkpoint transposition buffer
+        // staged y rows (see YRS): consumer hardware wave c = hwid of the workgroup's ncw = 4 (2 in split mode) owns bytes 32 c .. + 31
+        // of a row piece of 32 ncw bytes and, at the flush, rows (64 / ncw) c .. of the group
+        char* const ys = smem + 2 * GRP_BYTES + (GN ? 4096 : 0) + CKX_BYTES;
+        const int ylsh = a.split ? 2 : 3;                          // log2(lanes per staged row piece: 16-byte chunks)
+        auto stage_y = [&](int grp_, int blk, uint2 yb) {
+            *reinterpret_cast<uint2*>(ys + (grp_ & 1) * YS_BYTES + (BLK * blk + x) * YRS + 32 * hwid + 8 * g) = yb;
+        };
+        auto flush_y = [&](int grp_) {     // after the barrier that closed group grp_: every consumer's pieces of it are in the image
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (GRP >> (ylsh - 1)) * hwid + (64 >> ylsh) * i + (lane >> ylsh), chunk = lane & ((1 << ylsh) - 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(ys + (grp_ & 1) * YS_BYTES + row * YRS + 16 * chunk);
+                const unsigned off = (unsigned)(tokmap(grp_ * GRP + row, REV_Y) * a.C + 32 * part + 8 * chunk) * 2u;
+                buf_store16(rs_y, off, v);                         // (tokens past the end: dropped by the bounds check)
+            }
+        };
         const unsigned gn_bytes = (GN && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
         const rsrc_t rs_gate = make_rsrc(GN ? reinterpret_cast<const bf16_t*>(a.gn_gate) + base : nullptr, gn_bytes);
         const rsrc_t rs_out = make_rsrc(GN ? reinterpret_cast<bf16_t*>(a.gn_out) + base : nullptr, gn_bytes);
@@ -351,8 +412,11 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             }
         };
         __syncthreads();
+        constexpr bool STAGE_Y = !STATE_ONLY && !GN;              // (bf16 y of this launch goes through the staged rows; a y_f32 first half stores directly)
+        const bool staged = STAGE_Y && (ACC || !a.y_f32);
         for (int grp = 0; grp < ngrp; ++grp) {
             WKV6_T(ts0);
+            if (staged && grp > 0) flush_y(grp - 1);
             if constexpr (ACC) acc_request(grp + 1, acc_nxt);     // (past the last group: past the end of the resource, reads zero)
 
             // Rolled (runtime trip count): a fully unrolled 4-block body is no faster.  -DWKV6_FWD_UNROLL builds the unrolled
@@ -398,12 +462,14 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 // ALL of the block's LDS operands are requested here, in one go, and the scheduler may not sink them: left to itself hipcc
                 // issues each read right in front of its use, and with two waves on a SIMD every one of the ~8 round trips of a block
                 // was exposed (the consumers' 5.7 k cycles per group were LDS latency, not issue: profiles/r04_fwd_prefetch.txt).
-                const s4v vf = tr_read(bb + A_V * ARR + troff + 32 * wv);
+                typedef short s8v __attribute__((ext_vector_type(8)));
+                const b8v vf = __builtin_bit_cast(b8v, __builtin_shufflevector(tr_read(bb + A_V * ARR + troff + 32 * wv),
+                                                                               tr_read(bb + A_V * ARR + troff + 32 * wv + 4 * RSB), 0, 1, 2, 3, 4, 5, 6, 7));
                 [[maybe_unused]] uint4 scp = {};
                 [[maybe_unused]] float4 pm0[2] = {}, pm1[2] = {};
                 [[maybe_unused]] b8v pzh[2] = {}, pzl[2] = {};
                 if constexpr (!STATE_ONLY) {
-                    scp = *reinterpret_cast<const uint4*>(bb + OFF_SC + lane * 16);
+                    scp = *reinterpret_cast<const uint4*>(bb + scoff);
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         pm0[s] = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g) * 4);
@@ -413,27 +479,23 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                         pzl[s] = ld_b8(bb + A_RL * ARR + off);
                     }
                 }
-                s4v pkh[4], pkl[4];
+                b8v pk8[4];                                         // Khat (hi | lo along K) of tile `it`
                 float4 pd16[4], pdm[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    pkh[it] = tr_read(bb + A_KH * ARR + trow + tile_tr(it));
-                    pkl[it] = tr_read(bb + A_KL * ARR + trow + tile_tr(it));
+                    pk8[it] = __builtin_bit_cast(b8v, __builtin_shufflevector(tr_read(bb + A_KH * ARR + trow + tile_tr(it)),
+                                                                              tr_read(bb + A_KH * ARR + trow + tile_tr(it) + 4 * RSB), 0, 1, 2, 3, 4, 5, 6, 7));
                     pd16[it] = *reinterpret_cast<const float4*>(bb + OFF_E16 + (tile_ch(it) + 8 * g) * 4);
                     pdm[it] = *reinterpret_cast<const float4*>(bb + OFF_E16M8 + (tile_ch(it) + 8 * g) * 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!STATE_ONLY) {
-                    // (1) masked transposed scores, prepared by the producer of this block
-                    const s4v sc_hi = __builtin_bit_cast(s4v, make_uint2(scp.x, scp.y));
-                    const s4v sc_lo = __builtin_bit_cast(s4v, make_uint2(scp.z, scp.w));
-                    // (2) y^T[j][a] = sum_b V[b][j] sc[b][a]
-                    // Two accumulators: a 16x16x16 MFMA that takes the result of a 16x16x32 one as SrcC (or the reverse)
-                    // fewer than 5 wait states later reads stale registers on gfx950, and hipcc 7.2 does not pad that
-                    // case ("mixed-shape accumulation"); chains of one shape are interlocked.
-                    f4v yt = {0.f, 0.f, 0.f, 0.f}, yi = {0.f, 0.f, 0.f, 0.f};
-                    yi = mfma16(vf, sc_hi, yi);
-                    yi = mfma16(vf, sc_lo, yi);
+                    // (1) masked transposed scores, prepared by the producer of this block: hi | lo along K
+                    // (2) y^T[j][a] = sum_b V[b][j] sc[b][a]: (V | V) x (sc_hi ; sc_lo), one MFMA.  Every MFMA of this wave is a
+                    // 16x16x32 now, so one accumulator chain serves (2) and (3) (a 16x16x16 MFMA taking a 16x16x32 result as SrcC
+                    // fewer than 5 wait states later reads stale registers on gfx950: DESIGN.md section 4, "mixed-shape accumulation").
+                    f4v yt = {0.f, 0.f, 0.f, 0.f};
+                    yt = mfma32(vf, __builtin_bit_cast(b8v, scp), yt);
                     // (3) y^T[j][a] += sum_i (E8 S)[i][j] Rhat[a][i]; k-slot (s, g, e) <-> channel 32s + 8g + e
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -453,11 +515,12 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                     }
                     {   // store: lane holds y[token x][j = 16wv + 4g + q]
                         const int p = grp * GRP + blk * BLK + x;
-                        float o[4] = {yt[0] + yi[0], yt[1] + yi[1], yt[2] + yi[2], yt[3] + yi[3]};
+                        float o[4] = {yt[0], yt[1], yt[2], yt[3]};
                         if (!ACC && !a.y_f32) {                          // plain store: tokens past the end are dropped by the hardware
                             const unsigned off = (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g) * 2u;
                             const uint2 yb = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
-                            buf_store8(rs_y, off, yb);                   // (a null y: zero-sized resource, the store is dropped)
+                            if constexpr (GN) buf_store8(rs_y, off, yb);   // (a null y: zero-sized resource, the store is dropped)
+                            else stage_y(grp, blk, yb);
                             if constexpr (GN) {
                                 const float yr[4] = {bf_lo(yb.x), bf_hi(yb.x), bf_lo(yb.y), bf_hi(yb.y)};
                                 gn_off[blk] = off;
@@ -474,17 +537,15 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                             const unsigned idx = (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g);
                             if constexpr (ACC) acc_add(acc_cur[blk], o);          // requested a group ago
                             if (!ACC && a.y_f32) buf_store16f(rs_yf, idx * 4u, o);
-                            else buf_store8(rs_y, idx * 2u, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
+                            else stage_y(grp, blk, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
                         }
                     }
                 }
                 // (4) S[it] <- E16 (.) S[it] + E16m8 (.) (Khat^T V)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const s4v kh = pkh[it], kl = pkl[it];
                     f4v o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma16(kh, vf, o);
-                    o = mfma16(kl, vf, o);
+                    o = mfma32(pk8[it], vf, o);                      // (Khat_hi | Khat_lo)^T (V ; V)
                     const float4 d16 = pd16[it], dm = pdm[it];
                     St[it][0] = fmaf(d16.x, St[it][0], dm.x * o[0]);
                     St[it][1] = fmaf(d16.y, St[it][1], dm.y * o[1]);
@@ -507,6 +568,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1);
             if constexpr (GN) gn_finish(grp);
         }
+        if (staged && ngrp > 0) flush_y(ngrp - 1);                // (the loop's last barrier closed the last group)
         if (a.s_out) {
             const long so_ = ((long)b * a.H + h) * HEAD * HEAD + (long)(16 * wv + x) * HEAD + 8 * g;
 #pragma unroll
@@ -554,7 +616,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_pair_kernel(const ScanArgs a0, 
 
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (size_t)GRP_BYTES + (GN ? 4096 : 0) + CKX_BYTES;
+    constexpr size_t lds = 2 * (size_t)GRP_BYTES + (GN ? 4096 : 0) + CKX_BYTES + 2 * YS_BYTES;
     static LdsAttrOnce attr;                   // per instantiation and device
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), lds)) return e;
     if (a.split) hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), dim3(2 * a.B * a.H), dim3(384), lds, st, a);
@@ -601,7 +663,7 @@ hipError_t launch_chunk_fwd_pair(const ScanArgs& a0_, const ScanArgs& a1_, hipSt
     }
     ScanArgs a0 = a0_, a1 = a1_;
     a0.split = a1.split = 0;
-    constexpr size_t lds = 2 * (size_t)GRP_BYTES + CKX_BYTES;
+    constexpr size_t lds = 2 * (size_t)GRP_BYTES + CKX_BYTES + 2 * YS_BYTES;
     static LdsAttrOnce attr_raw, attr_ew;
     if (a0.wkind == 1) {
         if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_fwd_pair_kernel<true>), lds)) return e;

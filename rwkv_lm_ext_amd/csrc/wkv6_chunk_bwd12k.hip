@@ -593,8 +593,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         // Checkpoint of the 64-token pair that holds stage `stg`: the forward wrote it in this wave's register order
         // ([row wave][jt][lane][4], wkv6_scan.h), so the slice is four coalesced 16-byte loads per lane straight into
         // registers.  Requested behind a stage's pre-phase (the registers of the stage's own states are dead by then) for the NEXT
-        // stage: the latency runs under the chain, the barrier and the next stage's tile work.  Both stages of a pair read the
-        // same checkpoint; the second read comes from the L2.
+        // stage: the latency runs under the chain, the barrier and the next stage's tile work.  Both stages of a pair use the
+        // same checkpoint: requested once, ahead of the odd stage, and kept in CK for the even one.
         const unsigned nslots = ((unsigned)a.T + CKT - 1) / CKT;
         // (two-level scan over T: this batch row is segment b % S of sequence b / S; the S segments' slots are consecutive -- the
         // whole sequence's ordinary checkpoint layout, exactly as the forward wrote them: wkv6_chunk.hip)
@@ -826,7 +826,11 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 fetch_old(3, rs_gw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw[blk]);
             }
             WKV6_T5(2, tp0);
-            if (grp > 0) request_ckpt(grp - 1);
+            // The even stage of a pair enters with the pair's checkpoint itself -- which its odd stage left untouched in CK (the rebuild
+            // above writes ST[0], not CK): only an even stage requests a new one.  (Rounds 4: both stages read it, the second from the
+            // L2 -- 16 KB per pair and workgroup through the CU's vector-memory pipe, which these kernels keep ~80 % busy:
+            // profiles/r05_memory_pipe.md; same-box -1 %.)
+            if (grp > 0 && !(grp & 1)) request_ckpt(grp - 1);
             WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
             if constexpr (!SPLIT) {
                 WKV6_EV(2);

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Timing-only experiment builds of the chunked kernels that do NOT live in the product sources: the sources are
+# copied to build_ab/<name>_src, patched there, and compiled to build_ab/<name>/lib.so (use with RWKV_AMD_LIB; results are WRONG).
+#   bash tools/build_exp_variant.sh nostore      # backward: every gradient store dropped by the hardware bounds check (zero-sized resources)
+#   bash tools/build_exp_variant.sh noloads      # backward: ... and the r, k, v, w, gy loads too (zero-sized resources return 0): only checkpoints move
+set -e
+name=$1; flags=$2
+src=build_ab/${name}_src; rm -rf $src; mkdir -p $src/rwkv_lm_ext_amd; cp -r rwkv_lm_ext_amd/csrc $src/rwkv_lm_ext_amd/; cp -r include $src/
+f=$src/rwkv_lm_ext_amd/csrc/wkv6_chunk_bwd12k.hip
+case $name in
+  nostore) python3 - "$f" <<'PY'
+import sys
+p = sys.argv[1]; s = open(p).read()
+old = "    const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);"
+assert old in s
+s = s.replace(old, "    const rsrc_t rs_gr = make_rsrc(ogr, 0u), rs_gk = make_rsrc(ogk, 0u), rs_gv = make_rsrc(ogv, 0u), rs_gw = make_rsrc(ogw, 0u);")
+open(p, "w").write(s)
+PY
+  ;;
+  noloads) python3 - "$f" <<'PY'
+import sys
+p = sys.argv[1]; s = open(p).read()
+old = "    const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;"
+assert old in s
+s = s.replace(old, "    const unsigned nbytes = 0u;")
+open(p, "w").write(s)
+PY
+  ;;
+  *) echo "unknown experiment $name"; exit 1;;
+esac
+d=build_ab/$name; mkdir -p $d; rm -f $d/*.o
+for c in $src/rwkv_lm_ext_amd/csrc/*.hip; do
+    b=$(basename $c .hip)
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-strict-aliasing $flags -c $c -o $d/$b.o &
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o $d/lib.so $d/*.o
+echo built $d/lib.so

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(768) void bwd_shapes(const char* const* in, char* c
                 const long off = st + (long)(8 * wv + (lane >> 3)) * row + 16 * (lane & 7);
                 acc ^= ((const uint4*)(in[2] + off))->x ^ ((const uint4*)(in[4] + off))->y;
             }
-            if (!(WIDE & 2) && SHAPE == 1) {                      // 32-byte pieces, 16 B per lane, the stage's 32 tokens in one instruction
+            if (SHAPE == 4) {                                     // loads only
+            } else if (!(WIDE & 2) && SHAPE == 1) {                      // 32-byte pieces, 16 B per lane, the stage's 32 tokens in one instruction
                 const long so = st + (long)(lane >> 1) * row + 32 * wv + 16 * (lane & 1);
                 *(uint4*)(out[2] + so) = make_uint4(acc, s, lane, wv);
             } else if (!(WIDE & 2) && SHAPE == 2) {               // 64-byte pieces (a wave pair's 32 channels), 16 B per lane, 16 tokens per instruction
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(768) void bwd_shapes(const char* const* in, char* c
                 *(uint4*)(out[2] + off) = make_uint4(acc, s, lane, wv);
             }
         } else {                                                 // row waves: gr, gk, gw stores (out 0, 1, 3)
-            if (!(WIDE & 2) && SHAPE == 1) {
+            if (SHAPE == 4) {
+            } else if (!(WIDE & 2) && SHAPE == 1) {
                 const long so = st + (long)(lane >> 1) * row + 32 * wave + 16 * (lane & 1);
                 *(uint4*)(out[0] + so) = make_uint4(s, lane, wave, 0);
                 *(uint4*)(out[1] + so) = make_uint4(s, lane, wave, 1);
@@ -170,6 +172,90 @@ __global__ __launch_bounds__(768) void bwd_shapes(const char* const* in, char* c
                 *(uint4*)(out[0] + off) = make_uint4(s, lane, wave, 0);
                 *(uint4*)(out[1] + off) = make_uint4(s, lane, wave, 1);
                 *(uint4*)(out[3] + off) = make_uint4(s, lane, wave, 3);
+            }
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+
+// The 8-wave forward's OWN instruction shapes, nothing else (round 5): per 64-token group of a (batch, head)
+//   4 "producer" waves (wave = 16-token block): r, k, v, w as 8 bytes per lane, 16 lanes = one 128-byte row, 4 rows per instruction,
+//     4 instructions per tensor (lane = 4 channels x tokens 4 tq .. 4 tq + 3), the next group's loads in flight;
+//   4 "consumer" waves (wave = 16 of the 64 value channels): y stores per block, 8 bytes per lane, 4 lanes = 32-byte pieces of 16
+//     token rows; and per group one fp32 state checkpoint, four 16-byte-per-lane stores of 1 KB contiguous each.
+// WIDE & 1: loads as 16 bytes per lane (8 lanes = one row, 8 rows per instruction, 2 instructions per tensor);
+// WIDE & 2: y as full 128-byte rows, 16 bytes per lane (a consumer wave stores 16 token rows of the group: 2 instructions per group);
+// WIDE & 4: no checkpoint stores.
+template <int WIDE>
+__global__ __launch_bounds__(512) void fwd_shapes(const char* const* in, char* const* out, float* ckpt, int T, int C, int H, unsigned* sink)
+{
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long base = ((long)b * T * C + (long)h * 64) * 2;      // bytes
+    const long row = (long)C * 2;
+    unsigned acc = 0;
+    const int ng = T / 64;
+    if (wave >= 4) {
+        const int wv = wave - 4;
+        if (!(WIDE & 1)) {
+            uint2 cur[4][4], nxt[4][4];
+            auto load = [&](int g, uint2 (&r)[4][4]) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const long off = base + (long)(64 * g + 16 * wv + 4 * (lane >> 4) + tt) * row + 8 * (lane & 15);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r[k][tt] = *(const uint2*)(in[k] + off);
+                }
+            };
+            load(0, cur);
+            for (int g = 0; g < ng; ++g) {
+                if (g + 1 < ng) load(g + 1, nxt);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) { acc ^= cur[k][tt].x; acc += cur[k][tt].y; cur[k][tt] = nxt[k][tt]; }
+            }
+        } else {
+            uint4 cur[4][2], nxt[4][2];
+            auto load = [&](int g, uint4 (&r)[4][2]) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const long off = base + (long)(64 * g + 16 * wv + 2 * (lane >> 3) + tt) * row + 16 * (lane & 7);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r[k][tt] = *(const uint4*)(in[k] + off);
+                }
+            };
+            load(0, cur);
+            for (int g = 0; g < ng; ++g) {
+                if (g + 1 < ng) load(g + 1, nxt);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) { acc ^= cur[k][tt].x ^ cur[k][tt].z; acc += cur[k][tt].y + cur[k][tt].w; cur[k][tt] = nxt[k][tt]; }
+            }
+        }
+    } else {
+        const int wv = wave, x = lane & 15, g4 = lane >> 4;
+        float* const ck = ckpt + (long)blockIdx.x * ng * 4096;
+        for (int g = 0; g < ng; ++g) {
+            if (!(WIDE & 4)) {
+#pragma unroll
+                for (int wb = 0; wb < 4; ++wb)
+                    *(uint4*)(ck + (long)g * 4096 + ((wb * 4 + wv) * 64 + lane) * 4) = make_uint4(g, lane, wv, wb);
+            }
+            if (!(WIDE & 2)) {
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    const long so = base + (long)(64 * g + 16 * blk + x) * row + 32 * wv + 8 * g4;
+                    *(uint2*)(out[0] + so) = make_uint2(g, lane);
+                }
+            } else {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const long so = base + (long)(64 * g + 16 * wv + 8 * half + (lane >> 3)) * row + 16 * (lane & 7);
+                    *(uint4*)(out[0] + so) = make_uint4(g, lane, wv, half);
+                }
             }
         }
     }
@@ -238,12 +324,13 @@ int main()
         hipMemcpy(dout, bufs + 5, 4 * sizeof(void*), hipMemcpyHostToDevice);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         const double bytes = (double)B * T * C * 2 * 9;
-        for (int wide = 0; wide < 7; ++wide) {
+        for (int wide = 0; wide < 8; ++wide) {
             float best = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {
                 hipEventRecord(e0);
                 for (int it = 0; it < 20; ++it) {
-                    if (wide == 6) hipLaunchKernelGGL((bwd_shapes<0, 3>), dim3(B * H), dim3(768), 0, 0, (const char* const*)din, (char* const*)dout, T, C, H, sink);
+                    if (wide == 7) hipLaunchKernelGGL((bwd_shapes<0, 4>), dim3(B * H), dim3(768), 0, 0, (const char* const*)din, (char* const*)dout, T, C, H, sink);
+                    else if (wide == 6) hipLaunchKernelGGL((bwd_shapes<0, 3>), dim3(B * H), dim3(768), 0, 0, (const char* const*)din, (char* const*)dout, T, C, H, sink);
                     else if (wide == 5) hipLaunchKernelGGL((bwd_shapes<0, 2>), dim3(B * H), dim3(768), 0, 0, (const char* const*)din, (char* const*)dout, T, C, H, sink);
                     else if (wide == 4) hipLaunchKernelGGL((bwd_shapes<0, 1>), dim3(B * H), dim3(768), 0, 0, (const char* const*)din, (char* const*)dout, T, C, H, sink);
                     else if (wide == 3) hipLaunchKernelGGL(bwd_shapes<3>, dim3(B * H), dim3(768), 0, 0, (const char* const*)din, (char* const*)dout, T, C, H, sink);
@@ -255,10 +342,60 @@ int main()
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep >= 2 && ms / 20 < best) best = ms / 20;
             }
-            const char* names[7] = {"backward, 12 waves, the kernel's own instruction shapes:", "... loads as 16 B per lane / full rows, stores as the kernel's:",
+            const char* names[8] = {"backward, 12 waves, the kernel's own instruction shapes:", "... loads as 16 B per lane / full rows, stores as the kernel's:",
                                     "... loads as the kernel's, stores as 16 B per lane / full rows:", "... 16 B per lane and full rows everywhere:",
-                                    "... stores: 32-byte pieces but 16 B per lane (32 tokens per instruction):", "... stores: 64-byte pieces, 16 B per lane (16 tokens per instruction):", "... the kernel's shapes with non-temporal stores:"};
-            printf("%-66s %.4f ms  %.0f GB/s\n", names[wide], best, bytes / best / 1e6);
+                                    "... stores: 32-byte pieces but 16 B per lane (32 tokens per instruction):", "... stores: 64-byte pieces, 16 B per lane (16 tokens per instruction):", "... the kernel's shapes with non-temporal stores:", "... the kernel's loads, no stores at all (the bytes counted are the loads' 5/9):"};
+            printf("%-66s %.4f ms  %.0f GB/s\n", names[wide], best, (wide == 7 ? bytes * 5 / 9 : bytes) / best / 1e6);
+        }
+    }
+    {   // the 8-wave forward's own instruction shapes
+        const void** din; void** dout; unsigned* sink; float* ck;
+        hipMalloc(&din, 4 * sizeof(void*)); hipMalloc(&dout, sizeof(void*)); hipMalloc(&sink, 4); hipMalloc(&ck, (size_t)B * H * (T / 64) * 4096 * 4);
+        hipMemcpy(din, bufs, 4 * sizeof(void*), hipMemcpyHostToDevice);
+        hipMemcpy(dout, bufs + 4, sizeof(void*), hipMemcpyHostToDevice);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const char* names[6] = {"forward, 8 waves, the kernel's own instruction shapes (+ checkpoints):", "... loads as 16 B per lane (8 rows per instruction):",
+                                "... y as full 128-byte rows, 16 B per lane:", "... both:", "... the kernel's shapes without checkpoint stores:", "... both, without checkpoint stores:"};
+        const int modes[6] = {0, 1, 2, 3, 4, 7};
+        for (int m = 0; m < 6; ++m) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                hipEventRecord(e0);
+                for (int it = 0; it < 20; ++it) {
+#define FW(W) hipLaunchKernelGGL(fwd_shapes<W>, dim3(B * H), dim3(512), 0, 0, (const char* const*)din, (char* const*)dout, ck, T, C, H, sink)
+                    switch (modes[m]) { case 0: FW(0); break; case 1: FW(1); break; case 2: FW(2); break; case 3: FW(3); break; case 4: FW(4); break; default: FW(7); }
+                }
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep >= 2 && ms / 20 < best) best = ms / 20;
+            }
+            const double bytes = (double)B * T * C * 2 * 5 + ((modes[m] & 4) ? 0.0 : (double)B * T * C * 4);
+            printf("%-76s %.4f ms  %.0f GB/s\n", names[m], best, bytes / best / 1e6);
+        }
+    }
+    {   // the 8-wave forward's own instruction shapes
+        const void** din; void** dout; unsigned* sink; float* ck;
+        hipMalloc(&din, 4 * sizeof(void*)); hipMalloc(&dout, sizeof(void*)); hipMalloc(&sink, 4); hipMalloc(&ck, (size_t)B * H * (T / 64) * 4096 * 4);
+        hipMemcpy(din, bufs, 4 * sizeof(void*), hipMemcpyHostToDevice);
+        hipMemcpy(dout, bufs + 4, sizeof(void*), hipMemcpyHostToDevice);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const char* names[6] = {"forward, 8 waves, the kernel's own instruction shapes (+ checkpoints):", "... loads as 16 B per lane (8 rows per instruction):",
+                                "... y as full 128-byte rows, 16 B per lane:", "... both:", "... the kernel's shapes without checkpoint stores:", "... both, without checkpoint stores:"};
+        const int modes[6] = {0, 1, 2, 3, 4, 7};
+        for (int m = 0; m < 6; ++m) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                hipEventRecord(e0);
+                for (int it = 0; it < 20; ++it) {
+#define FW(W) hipLaunchKernelGGL(fwd_shapes<W>, dim3(B * H), dim3(512), 0, 0, (const char* const*)din, (char* const*)dout, ck, T, C, H, sink)
+                    switch (modes[m]) { case 0: FW(0); break; case 1: FW(1); break; case 2: FW(2); break; case 3: FW(3); break; case 4: FW(4); break; default: FW(7); }
+                }
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep >= 2 && ms / 20 < best) best = ms / 20;
+            }
+            const double bytes = (double)B * T * C * 2 * 5 + ((modes[m] & 4) ? 0.0 : (double)B * T * C * 4);
+            printf("%-76s %.4f ms  %.0f GB/s\n", names[m], best, bytes / best / 1e6);
         }
     }
     return 0;

@@ -47,10 +47,19 @@ for _ in range(30):
     if args.only != "fwd":
         bwd()
 out = {}
+probe = wkv6_op.ClockProbe(dev, n_slots=B * H) if os.environ.get("WKV6_CLOCKS", "0") == "1" else None   # in-run shader clocks (plain kernels)
 if args.only in ("both", "fwd"):
     out["fwd_ms"] = round(run(fwd, args.iters), 4)
 if args.only in ("both", "bwd"):
     out["bwd_ms"] = round(run(bwd, args.iters), 4)
+if probe is not None:
+    ck = probe.read()
+    probe.close()
+    out.update(ck)
+    if ck.get("fwd_ghz") and "fwd_ms" in out:
+        out["fwd_cycles_per_64_tokens"] = round(out["fwd_ms"] * 1e-3 * ck["fwd_ghz"] * 1e9 / ((T + 63) // 64))
+    if ck.get("bwd_ghz") and "bwd_ms" in out:
+        out["bwd_cycles_per_32_tokens"] = round(out["bwd_ms"] * 1e-3 * ck["bwd_ghz"] * 1e9 / ((T + 31) // 32))
 print(os.environ.get("ABL_NAME", "default"), out, flush=True)
 if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wave phase cycles of one backward launch
     import ctypes
@@ -67,17 +76,11 @@ if os.environ.get("WKV6_STAMP", "0") == "1":       # diagnostic library: per-wav
     print("forward, cycles per 64-token group and wave (avg over workgroups):")
     print("  consumers 0-3 = [body, barrier]   producers 4-7 = [load wait, prep, load issue, barrier]")
     for wv in range(8):
-        print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / ng):8.0f}" for k in range(4)))
+        print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / ng):8.0f}" for k in range(6)))
     buf.zero_()
     bwd()
     torch.cuda.synchronize()
     d = buf.view(B * H, 16, 8).double().mean(0)         # average over workgroups: [wave][phase]
-    if os.environ.get("WKV6_BWD", "") == "64":
-        nc = (T + 63) // 64
-        print("two-level backward, cycles per 64-token chunk and wave (avg over workgroups): [phase A, barrier, phase B, barrier, phase C, barrier]")
-        for wv in range(16):
-            print(f"  wave {wv:2d}: " + "  ".join(f"{(d[wv, k].item() / nc):8.0f}" for k in range(6)))
-        sys.exit(0)
     ns = (T + 31) // 32
     print("backward, cycles per 32-token stage and wave (avg over workgroups):")
     print("  row waves 0-3  = [tiles + ckpt wait, rebuild, pre-phase, chain, barrier]")
