@@ -3,6 +3,8 @@
 # copied to build_ab/<name>_src, patched there, and compiled to build_ab/<name>/lib.so (use with RWKV_AMD_LIB; results are WRONG).
 #   bash tools/build_exp_variant.sh nostore      # backward: every gradient store dropped by the hardware bounds check (zero-sized resources)
 #   bash tools/build_exp_variant.sh noloads      # backward: ... and the r, k, v, w, gy loads too (zero-sized resources return 0): only checkpoints move
+#   bash tools/build_exp_variant.sh fwd_nostore  # forward: y and checkpoint stores dropped
+#   bash tools/build_exp_variant.sh fwd_noloads  # forward: ... and the r, k, v, w loads too: no memory traffic at all
 set -e
 name=$1; flags=$2
 src=build_ab/${name}_src; rm -rf $src; mkdir -p $src/rwkv_lm_ext_amd; cp -r rwkv_lm_ext_amd/csrc $src/rwkv_lm_ext_amd/; cp -r include $src/
@@ -23,6 +25,21 @@ p = sys.argv[1]; s = open(p).read()
 old = "    const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;"
 assert old in s
 s = s.replace(old, "    const unsigned nbytes = 0u;")
+open(p, "w").write(s)
+PY
+  ;;
+  fwd_nostore|fwd_noloads) python3 - "$src/rwkv_lm_ext_amd/csrc/wkv6_chunk.hip" "$name" <<'PY'
+import sys
+p, name = sys.argv[1], sys.argv[2]; s = open(p).read()
+old = "(!STATE_ONLY && a.y && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);"
+assert old in s
+s = s.replace(old, "0u);")
+old = "a.ckpt ? nst * 16384u : 0u);"
+assert old in s
+s = s.replace(old, "0u);")
+if name == "fwd_noloads":
+    assert "ntok > 0 ? span * 2 + 128 : 0" in s and "ntok > 0 ? span * 4 + 256 : 0" in s
+    s = s.replace("ntok > 0 ? span * 2 + 128 : 0", "0").replace("ntok > 0 ? span * 4 + 256 : 0", "0")
 open(p, "w").write(s)
 PY
   ;;
