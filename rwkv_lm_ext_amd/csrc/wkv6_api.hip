@@ -590,10 +590,15 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
     a.lens = lens;
     a.zero_tail = 1;                          // y[t > L_b] = 0 (the reference leaves it uninitialised, Q2)
     a.ckpt = keep ? ws.scan[0] : nullptr;
+    ScanArgs a2 = a;
+    a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0;   // cuda/wkv6_bi_cuda.cu:71-111
+    a2.ckpt = keep ? ws.scan[1] : nullptr;
+    if (chunked) {          // both halves in one persistent launch (the fp32 partial of a row stays in the slot's scratch: L2 / Infinity Cache)
+        const hipError_t e = launch_chunk_fwd_bi(a, a2, nullptr, st);
+        if (e != hipErrorNotSupported) return to_rc(e);
+    }
     if (hipError_t e = run_fwd(a, flags, st)) return (int)e;
-    a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0;   // cuda/wkv6_bi_cuda.cu:71-111
-    a.ckpt = keep ? ws.scan[1] : nullptr;
-    return to_rc(run_fwd(a, flags, st));
+    return to_rc(run_fwd(a2, flags, st));
 }
 
 int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
@@ -623,6 +628,15 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
         // chunked bf16 path: the first half goes to fp32 side buffers, the second adds it and rounds once
         // (the reference accumulates `_gr[t] += F(gr)` in bf16, cuda/wkv6_bi_cuda.cu:199-200)
         for (int i = 0; i < 4; ++i) a.g_f32[i] = ws.side[i];
+    }
+    if (!(flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN))) {
+        // both halves in one persistent launch: the first half's four fp32 partials of a row stay in the slot's scratch
+        ScanArgs a1 = a, a2 = a;
+        a1.ckpt = ws.scan[0]; a2.ckpt = ws.scan[1];
+        a1.ckpt_valid = a2.ckpt_valid = (flags & WKV6_CKPT_VALID) ? 1 : 0;
+        a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.gu = nullptr;
+        const hipError_t e = launch_chunk_bwd_bi(a1, a2, nullptr, st);
+        if (e != hipErrorNotSupported) return to_rc(e);
     }
     if (hipError_t e = run_bwd(a, flags, ws.scan[0], st)) return (int)e;             // adjoint of the forward scan
     a.reverse = 1; a.use_u = 0; a.accumulate = 1; a.zero_tail = 0; a.gu = nullptr;   // adjoint of the reverse scan

@@ -62,7 +62,7 @@ constexpr int YS_BYTES = GRP * YRS;
 // chunk_fwd_pair_kernel (the two WKV problems of a bidirectional composition in ONE launch) on one of two.
 // CLK: the in-run clock probe (wkv6_set_clock_buffer) is compiled into the plain kernel only.
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false, bool CLK = false>
-__device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot)
+__device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot, const unsigned sslot = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2] | float [4 consumers][1024] | y rows [2][64][YRS]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -330,15 +330,19 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         // (profiles/r04_bi_acc_prefetch.txt).  The block loop is unrolled for this instantiation: static register indices.
         // (wkv6_bi's halves go through buffer resources over the row's first ntok tokens like the plain path: tokens past the end
         // read zero / are dropped by the hardware -- no per-lane predicates, no 64-bit address arithmetic)
-        const unsigned nb_y = (!STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * a.C : 0u;
-        const rsrc_t rs_yf = make_rsrc(a.y_f32 ? a.y_f32 + base : nullptr, (a.y_f32 && !STATE_ONLY && ntok > 0) ? nb_y * 4u + 256u : 0u);
+        // (one launch for both halves, chunk_fwd_bi_kernel: the fp32 side buffer is this workgroup slot's own scratch, [T][64] with a
+        // token stride of 64)
+        const unsigned ystr = a.side_compact ? (unsigned)HEAD : (unsigned)a.C;
+        const unsigned ych = a.side_compact ? 16u * (unsigned)hwid : 16u * (unsigned)wv;             // this consumer's channels in a side row
+        const rsrc_t rs_yf = make_rsrc(a.y_f32 ? a.y_f32 + (a.side_compact ? (long)sslot * a.T * HEAD : base) : nullptr,
+                                       (a.y_f32 && !STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * ystr * 4u + 256u : 0u);
         [[maybe_unused]] uint4 acc_cur[NBLK] = {}, acc_nxt[NBLK] = {};
         auto acc_request = [&](int grp_, uint4 (&dst)[NBLK]) {
 #pragma unroll
             for (int blk = 0; blk < NBLK; ++blk) {
                 const unsigned idx = (unsigned)(tokmap(grp_ * GRP + blk * BLK + x, REV_Y) * a.C + 16 * wv + 4 * g);
                 if (a.y_f32) {
-                    const float4 t = buf_load16f(rs_yf, idx * 4u);
+                    const float4 t = buf_load16f(rs_yf, ((unsigned)tokmap(grp_ * GRP + blk * BLK + x, REV_Y) * ystr + ych + 4u * g) * 4u);
                     dst[blk] = make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w));
                 } else {
                     const uint2 t = buf_load8(rs_y, idx * 2u);
@@ -468,7 +472,6 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 // ALL of the block's LDS operands are requested here, in one go, and the scheduler may not sink them: left to itself hipcc
                 // issues each read right in front of its use, and with two waves on a SIMD every one of the ~8 round trips of a block
                 // was exposed (the consumers' 5.7 k cycles per group were LDS latency, not issue: profiles/r04_fwd_prefetch.txt).
-                typedef short s8v __attribute__((ext_vector_type(8)));
                 const b8v vf = __builtin_bit_cast(b8v, __builtin_shufflevector(tr_read(bb + A_V * ARR + troff + 32 * wv),
                                                                                tr_read(bb + A_V * ARR + troff + 32 * wv + 4 * RSB), 0, 1, 2, 3, 4, 5, 6, 7));
                 [[maybe_unused]] uint4 scp = {};
@@ -540,9 +543,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                                     *reinterpret_cast<float*>(gn_stat + (grp & 1) * 2048 + ((wv * NBLK + blk) * 16 + x) * 8 + (g >> 1) * 4) = red;
                             }
                         } else {
-                            const unsigned idx = (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g);
                             if constexpr (ACC) acc_add(acc_cur[blk], o);          // requested a group ago
-                            if (!ACC && a.y_f32) buf_store16f(rs_yf, idx * 4u, o);
+                            if (!ACC && a.y_f32) buf_store16f(rs_yf, ((unsigned)tokmap(p, REV_Y) * ystr + ych + 4u * g) * 4u, o);
                             else stage_y(grp, blk, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
                         }
                     }
@@ -620,6 +622,31 @@ __global__ __launch_bounds__(512) void chunk_fwd_pair_kernel(const ScanArgs a0, 
     chunk_fwd_body<W_RAW, false, false, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);   // kernarg addresses
 }
 
+// Both halves of wkv6_bi in one persistent launch (cuda/wkv6_bi_cuda.cu:363-368 is one launch too): workgroup slot s walks the rows
+// s, s + slots, ... of the length-ordered batch x head list; per row the forward-direction scan leaves y in the slot's fp32 scratch
+// ([T][64], 128 KB at T = 512), the reversed-direction scan adds it and rounds once.
+// (one argument block: the reversed-direction problem differs from the forward-direction one in five fields)
+template <bool W_RAW>
+__global__ __launch_bounds__(512) void chunk_fwd_bi_kernel(const ScanArgs a1, float* const ckpt2)
+{
+    const unsigned n = (unsigned)(a1.B * a1.H);
+    // the rows are ordered by decreasing length (a.order): slot j takes row j of the first round of gridDim.x rows, row gridDim.x - 1 - j
+    // of the second, ... (boustrophedon), so that every slot gets long and short rows alike -- in plain round-robin order slot 0 would
+    // take the longest row of every round and the last slot the shortest (+-12 % of the mean at BASELINE configs[2])
+    for (unsigned it = 0; it * gridDim.x < n; ++it) {
+        const unsigned row = it * gridDim.x + ((it & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x);
+        if (row >= n) continue;                                     // (the last round may be short; workgroup-uniform)
+        chunk_fwd_body<W_RAW, false, false>(a1, row, blockIdx.x);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        ScanArgs a2 = a1;
+        a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.ckpt = ckpt2;
+        chunk_fwd_body<W_RAW, false, true>(a2, row, blockIdx.x);
+        __syncthreads();
+    }
+}
+
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = 2 * (size_t)GRP_BYTES + (GN ? 4096 : 0) + CKX_BYTES + 2 * YS_BYTES;
@@ -677,6 +704,31 @@ hipError_t launch_chunk_fwd_pair(const ScanArgs& a0_, const ScanArgs& a1_, hipSt
     } else {
         if (hipError_t e = attr_ew.ensure(reinterpret_cast<const void*>(chunk_fwd_pair_kernel<false>), lds)) return e;
         hipLaunchKernelGGL((chunk_fwd_pair_kernel<false>), dim3(2 * a0.B * a0.H), dim3(512), lds, st, a0, a1);
+    }
+    return hipGetLastError();
+}
+
+int bi_slots(int BH);       // wkv6_chunk_bwd12k.hip
+hipError_t launch_chunk_fwd_bi(const ScanArgs& a1_, const ScanArgs& a2_, int* slots, hipStream_t st)
+{
+    const int n = bi_slots(a1_.B * a1_.H);
+    if (slots) *slots = n;
+    if (!n || !a1_.y_f32 || a1_.gn_out || a1_.dsum || a1_.ckpt_segs) return hipErrorNotSupported;
+    if (!offsets_fit(a1_)) return hipErrorInvalidValue;
+    ScanArgs a1 = a1_, a2 = a2_;
+    a1.split = a2.split = 0;
+    a1.side_compact = a2.side_compact = 1;
+#ifdef WKV6_DEBUGBUF
+    a1.aux = a2.aux = reinterpret_cast<float*>(g_stamp_buffer);
+#endif
+    constexpr size_t lds = 2 * (size_t)GRP_BYTES + CKX_BYTES + 2 * YS_BYTES;
+    static LdsAttrOnce attr_raw, attr_ew;
+    if (a1.wkind == 1) {
+        if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_fwd_bi_kernel<true>), lds)) return e;
+        hipLaunchKernelGGL((chunk_fwd_bi_kernel<true>), dim3(n), dim3(512), lds, st, a1, a2.ckpt);
+    } else {
+        if (hipError_t e = attr_ew.ensure(reinterpret_cast<const void*>(chunk_fwd_bi_kernel<false>), lds)) return e;
+        hipLaunchKernelGGL((chunk_fwd_bi_kernel<false>), dim3(n), dim3(512), lds, st, a1, a2.ckpt);
     }
     return hipGetLastError();
 }

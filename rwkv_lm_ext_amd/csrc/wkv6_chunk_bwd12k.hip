@@ -122,7 +122,7 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 // CLK: the in-run clock probe (wkv6_set_clock_buffer) is compiled into the plain kernel only (it costs ~6 SGPRs, which the wkv6_bi
 // and pair instantiations do not have).
 template <bool W_RAW, int GEN, bool SPLIT, bool CLK = false>
-__device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot)
+__device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot, const unsigned sslot = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][RBLK_BYTES] | [3][SBLK][KBLK_BYTES] | tiles | G operand
     const int tid = threadIdx.x, lane = tid & 63;
@@ -152,14 +152,18 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // wkv6_bi's halves: the first (GEN == 1) writes its four gradients into fp32 side buffers (always there: checked at launch), the
     // second (GEN == 2) requests them ahead of the work whose result they meet, adds and rounds once.  Side buffers and outputs alike
     // go through buffer resources over the row's first ntok tokens: tokens past the end read zero / are dropped by the hardware.
-    const unsigned nbytes4 = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 4u + 256u : 0u;
-    const rsrc_t rs_side[4] = {make_rsrc(GEN && a.g_f32[0] ? a.g_f32[0] + base : nullptr, GEN && a.g_f32[0] ? nbytes4 : 0u),
-                               make_rsrc(GEN && a.g_f32[1] ? a.g_f32[1] + base : nullptr, GEN && a.g_f32[1] ? nbytes4 : 0u),
-                               make_rsrc(GEN && a.g_f32[2] ? a.g_f32[2] + base : nullptr, GEN && a.g_f32[2] ? nbytes4 : 0u),
-                               make_rsrc(GEN && a.g_f32[3] ? a.g_f32[3] + base : nullptr, GEN && a.g_f32[3] ? nbytes4 : 0u)};
+    // (one launch for both halves, chunk_bwd12k_bi_kernel: the side buffers are this workgroup slot's own scratch, [T][64] fp32 with
+    // a token stride of 64 -- written by the first half, read back by the second from the L2 / Infinity Cache, rewritten for the next row)
+    const long sbase = (GEN && a.side_compact) ? (long)sslot * a.T * HEAD : base;
+    const unsigned sstr = (GEN && a.side_compact) ? (unsigned)HEAD : (unsigned)a.C;      // elements between tokens in the side buffers
+    const unsigned nbytes4 = ntok > 0 ? (unsigned)(ntok - 1) * sstr * 4u + 256u : 0u;
+    const rsrc_t rs_side[4] = {make_rsrc(GEN && a.g_f32[0] ? a.g_f32[0] + sbase : nullptr, GEN && a.g_f32[0] ? nbytes4 : 0u),
+                               make_rsrc(GEN && a.g_f32[1] ? a.g_f32[1] + sbase : nullptr, GEN && a.g_f32[1] ? nbytes4 : 0u),
+                               make_rsrc(GEN && a.g_f32[2] ? a.g_f32[2] + sbase : nullptr, GEN && a.g_f32[2] ? nbytes4 : 0u),
+                               make_rsrc(GEN && a.g_f32[3] ? a.g_f32[3] + sbase : nullptr, GEN && a.g_f32[3] ? nbytes4 : 0u)};
     auto fetch_old = [&](int which, const rsrc_t& rs, int p, unsigned bit, int ch, float (&old)[4]) {
         if constexpr (GEN == 2) {
-            const unsigned idx = (unsigned)(tokmap(p, bit) * a.C + ch);
+            const unsigned idx = (unsigned)tokmap(p, bit) * sstr + (unsigned)ch;
             const float4 t = buf_load16f(rs_side[which], idx * 4u);   // (the halves of wkv6_bi always meet in the fp32 side buffers: checked at launch)
             old[0] = t.x; old[1] = t.y; old[2] = t.z; old[3] = t.w;
         }
@@ -213,7 +217,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // bf16 quad for `put`
     auto emit = [&](int which, int stg, int blk, unsigned bit, float (&o)[4], const float (&old)[4]) -> uint2 {
         if constexpr (GEN == 1) {
-            const unsigned idx = (unsigned)(tokmap(stg * STG + blk * BLK + x_, bit) * a.C + 16 * wv + 4 * g_);
+            const unsigned idx = (unsigned)tokmap(stg * STG + blk * BLK + x_, bit) * sstr + (unsigned)(16 * wv + 4 * g_);
             buf_store16f(rs_side[which], idx * 4u, o);
             return make_uint2(0u, 0u);
         }
@@ -1257,6 +1261,34 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_pair_kernel(const ScanArgs a
     chunk_bwd12k_body<W_RAW, 0, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);
 }
 
+// Both halves of wkv6_bi in one persistent launch (cuda/wkv6_bi_cuda.cu:363-377 runs one forward and three backward launches): workgroup
+// slot s walks the rows s, s + slots, ... of the (length-ordered) batch x head list; per row the forward-direction adjoint goes to the slot's
+// fp32 scratch (GEN = 1), the reversed-direction adjoint adds it and rounds once (GEN = 2).  The partials of a row are 4 x T x 256 B
+// (512 KB at T = 512) per slot, 128 MB for 256 slots: written and read back within ~50 us by the same CU, they live in the L2 and the
+// Infinity Cache instead of making a round trip through HBM (two launches: 16 + 16 B per token-channel).
+// (ONE argument block: the reversed-direction problem is the forward-direction one with `reverse`, no bonus, accumulation, no tail
+// zeroing, no gu and its own checkpoints -- two blocks kept both in scalar registers across the row loop and spilled 200 of them.)
+template <bool W_RAW>
+__global__ __launch_bounds__(768) void chunk_bwd12k_bi_kernel(const ScanArgs a1, float* const ckpt2)
+{
+    const unsigned n = (unsigned)(a1.B * a1.H);
+    // the rows are ordered by decreasing length (a.order): slot j takes row j of the first round of gridDim.x rows, row gridDim.x - 1 - j
+    // of the second, ... (boustrophedon), so that every slot gets long and short rows alike -- in plain round-robin order slot 0 would
+    // take the longest row of every round and the last slot the shortest (+-12 % of the mean at BASELINE configs[2])
+    for (unsigned it = 0; it * gridDim.x < n; ++it) {
+        const unsigned row = it * gridDim.x + ((it & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x);
+        if (row >= n) continue;                                     // (the last round may be short; workgroup-uniform)
+        chunk_bwd12k_body<W_RAW, 1, false>(a1, row, blockIdx.x);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's partial stores are out ...
+        __syncthreads();                                            // ... and every wave's (the LDS tags are re-armed behind this barrier)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        ScanArgs a2 = a1;
+        a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.gu = nullptr; a2.ckpt = ckpt2;
+        chunk_bwd12k_body<W_RAW, 2, false>(a2, row, blockIdx.x);
+        __syncthreads();
+    }
+}
+
 template <bool W_RAW, int GEN> hipError_t launch_bwd12k_inst(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = BWD12K_LDS;
@@ -1326,6 +1358,45 @@ hipError_t launch_chunk_bwd(const ScanArgs& a_, hipStream_t st)
         if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
     }
     return launch_chunk_bwd12k(a, st);
+}
+
+int bi_slots(int BH)
+{
+    if (want_split(BH)) return 0;
+    if (const char* e = getenv("WKV6_BI_FUSED")) { if (atoi(e) == 0) return 0; }     // A/B switch: 0 = the halves as two launches
+    const int cus = cu_count();
+    return cus > 0 ? (BH < cus ? BH : cus) : 0;
+}
+
+hipError_t launch_chunk_bwd_bi(const ScanArgs& a1_, const ScanArgs& a2_, int* slots, hipStream_t st)
+{
+    const int n = bi_slots(a1_.B * a1_.H);
+    if (slots) *slots = n;
+    if (!n || !a1_.ckpt || !a2_.ckpt || a1_.g_in || a1_.rc_in) return hipErrorNotSupported;
+    if (a1_.wkind != 1 && ((long)a1_.T + 64) * a1_.C >= (1L << 30)) return hipErrorInvalidValue;
+    ScanArgs a1 = a1_, a2 = a2_;
+    for (ScanArgs* a : {&a1, &a2}) {
+        a->split = 0;
+        if (!a->ckpt_valid) {                   // self-contained: this half's state pass first (same inputs, no outputs)
+            ScanArgs sp = *a;
+            sp.y = nullptr; sp.y_f32 = nullptr; sp.s_out = nullptr; sp.accumulate = 0; sp.zero_tail = 0;
+            if (hipError_t e = launch_chunk_state_pass(sp, st)) return e;
+        }
+        a->side_compact = 1;
+#ifdef WKV6_DEBUGBUF
+        a->aux = reinterpret_cast<float*>(g_stamp_buffer);
+#endif
+    }
+    constexpr size_t lds = BWD12K_LDS;
+    static LdsAttrOnce attr_raw, attr_ew;
+    if (a1.wkind) {
+        if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_bwd12k_bi_kernel<true>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_bi_kernel<true>), dim3(n), dim3(768), lds, st, a1, a2.ckpt);
+    } else {
+        if (hipError_t e = attr_ew.ensure(reinterpret_cast<const void*>(chunk_bwd12k_bi_kernel<false>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_bi_kernel<false>), dim3(n), dim3(768), lds, st, a1, a2.ckpt);
+    }
+    return hipGetLastError();
 }
 
 // Backward of both problems of a bidirectional composition in one launch; both checkpoint sets must come from the forward

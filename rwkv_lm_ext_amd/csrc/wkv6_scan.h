@@ -89,6 +89,8 @@ struct ScanArgs {
                                       // entering this row (= segment) from the future, or null (zero)
     const float* rc_in;               // ... and fp32 [B,C]: the gw suffix sum at the segment's end, sum_{s >= end} (a_s - b_s) =
                                       // Phi[i] = sum_j G[i][j] S[i][j] at the boundary, or null (zero)
+    int side_compact;                 // chunked wkv6_bi halves in one launch: y_f32 / g_f32 are per-workgroup scratch, fp32 [slot][T][64]
+                                      // (token stride 64), instead of [B,T,C] arrays addressed by (batch, head)
     unsigned long long* clk;          // chunked kernels: clock stamps of wave 0 of workgroup slots < clk_slots ({memtime, memrealtime} at start
     int clk_slots;                    //   and end: wkv6_set_clock_buffer, include/wkv6_amd.h), or null (the default: no stamp executes)
     int split;                        // chunked kernels, set by the launcher when B*H leaves half the chip idle: two workgroups per
@@ -121,6 +123,12 @@ hipError_t launch_chunk_fwd_pair(const ScanArgs& a0, const ScanArgs& a1, hipStre
 hipError_t launch_chunk_bwd_pair(const ScanArgs& a0, const ScanArgs& a1, hipStream_t st);
 // chunked MFMA backward (bf16 I/O only): state pass + reverse pass; a.ckpt must hold chunk_ckpt_floats() floats
 hipError_t launch_chunk_bwd(const ScanArgs& a, hipStream_t st);
+// both halves of wkv6_bi in ONE persistent launch (one workgroup slot per CU walks (batch, head) rows: first half into the slot's fp32
+// scratch, second half adds it and rounds): a1 / a2 = the forward-direction / reversed-direction problem; hipErrorNotSupported where
+// the launch does not apply (two workgroups per pair) -- the caller then runs the halves as two launches
+hipError_t launch_chunk_fwd_bi(const ScanArgs& a1, const ScanArgs& a2, int* slots, hipStream_t st);
+hipError_t launch_chunk_bwd_bi(const ScanArgs& a1, const ScanArgs& a2, int* slots, hipStream_t st);
+int bi_slots(int BH);                        // workgroup slots such a launch uses (0: does not apply)
 hipError_t launch_chunk_bwd12k(const ScanArgs& a, hipStream_t st);    // reverse pass over 64-token row-order checkpoints, a.split as given (wkv6_chunk_bwd12k.hip)
 size_t chunk_ckpt_floats(int B, int T, int H);
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // state recurrence only (s_out, ckpt, dsum)
