@@ -30,7 +30,30 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI3
 FWD_BYTES, BWD_BYTES = 10, 18   # per token-channel
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_final_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_final_pmc.json")
+
+
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries below us write there too (RCCL prints a five-line version banner when its
+    first communicator is made): file descriptor 1 is pointed at stderr for the whole run and the line goes out through a saved
+    duplicate of the original descriptor (emit)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
 
 
 def pmc_from_file():
@@ -268,7 +291,7 @@ def bench_dp_lora(args, rank, world, dev, dist):
     elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
     if rank == 0:
         tokens = 3 * bs * T                         # per GPU and step
-        print(json.dumps({
+        emit(({
             "metric": "LoRA bi-encoder training tokens/sec (RWKV-x060-1B6 shape, T=512, DP, RCCL grad all-reduce)",
             "value": round(world * tokens * args.steps / elapsed, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": 1,
@@ -279,7 +302,7 @@ def bench_dp_lora(args, rank, world, dev, dist):
                        "seq_len": T, "per_gpu_batch": bs, "global_batch": bs * world,
                        "sequences_per_gpu_step": 3 * bs, "grad_checkpointing": True,
                        "parallelism": f"dp{world} (DDP, one bucketed all-reduce of the trainable gradients per step)",
-                       "allreduce_bytes_per_step": msg_bytes}}), flush=True)
+                       "allreduce_bytes_per_step": msg_bytes}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -376,6 +399,7 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -487,7 +511,7 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -579,6 +579,9 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
         lens = ws.lens;
     }
     const bool chunked = !(flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN));
+    // the chunked halves address their fp32 side buffers with 32-bit byte offsets (buffer resources): (T + 128) C fp32 elements must
+    // stay below 2^32 bytes (where two workgroups serve a pair the side buffers are [B,T,C] arrays; the one-launch path's are [T][64])
+    if (chunked && ((long)T + 128) * C >= (1L << 30)) return WKV6_EUNSUPPORTED;
     const bool keep = (flags & WKV6_BI_KEEP_CKPT) && chunked;
     ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
     if (chunked && B > 1 && B <= 4096) {
@@ -616,6 +619,7 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
         hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, ws.lens, T);
         lens = ws.lens;
     }
+    if (!(flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) && ((long)T + 128) * C >= (1L << 30)) return WKV6_EUNSUPPORTED;   // (as in the forward)
     ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
     a.gy = gy; a.gr = gr; a.gk = gk; a.gv = gv; a.gw = gw; a.gu = gu;
     a.lens = lens;

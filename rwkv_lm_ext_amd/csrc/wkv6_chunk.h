@@ -114,15 +114,21 @@ __device__ __forceinline__ b8v ld_b8_2x4(const char* p0, const char* p1)
 // split 4 floats into packed bf16 hi and lo parts.  lo = x - float(hi) is formed by v_dot2(c)_f32_bf16 straight from
 // the packed hi pair (hi.(-1,0) + x, exact: every partial result is representable), ~2 cycles per element where the
 // unpack (shift 4, and 2.3) + subtract (2) path costs ~6 (issue rates: DESIGN.md section 4).
-__device__ __forceinline__ void split4(const float (&x)[4], uint2& hi, uint2& lo)
+// The two constants of the trick -- (-1, 0) and (0, -1) as packed bf16 -- are made ONCE per wave (split_const) and handed to every
+// split: kept opaque (hipcc 7.2 folds such a pair into the inline constant -1.0, which the hardware does not expand to (bf16 -1, 0) for
+// this instruction: results were off by whole terms), they used to be re-materialised by two v_mov_b32 in front of every call --
+// ~45 of the backward's 1058 vector instructions per SIMD and stage, ~80 of the forward's 913 per group.
+struct SplitConst { unsigned c10, c01; };
+__device__ __forceinline__ SplitConst split_const()
+{
+    unsigned c10 = 0x0000bf80u, c01 = 0xbf800000u;
+    asm volatile("" : "+v"(c10), "+v"(c01));
+    return SplitConst{c10, c01};
+}
+__device__ __forceinline__ void split4(const float (&x)[4], uint2& hi, uint2& lo, const SplitConst& sc)
 {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    // (-1, 0) and (0, -1) as packed bf16.  Kept opaque: hipcc 7.2 folds such a pair into the inline constant -1.0, which
-    // the hardware does not expand to (bf16 -1, 0) for this instruction (results were off by whole terms).
-    unsigned c10 = 0x0000bf80u, c01 = 0xbf800000u;
-    asm("" : "+v"(c10));
-    asm("" : "+v"(c01));
-    const bf2 m10 = __builtin_bit_cast(bf2, c10), m01 = __builtin_bit_cast(bf2, c01);
+    const bf2 m10 = __builtin_bit_cast(bf2, sc.c10), m01 = __builtin_bit_cast(bf2, sc.c01);
     hi.x = pack_bf2(x[0], x[1]);
     hi.y = pack_bf2(x[2], x[3]);
 #ifdef WKV6_SPLIT_NODOT

@@ -66,6 +66,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2] | float [4 consumers][1024] | y rows [2][64][YRS]
     const int tid = threadIdx.x, lane = tid & 63;
+    const SplitConst spc = split_const();
     // a.split (B*H <= half the CUs): two 6-wave workgroups per (batch, head) on two CUs, each with all four producers and two
     // of the four consumers (value columns [32 part, 32 part + 32)): hardware wave w plays consumer 2 part + w for w < 2 and
     // producer w - 2 (wave id 4 + w - 2) otherwise.  The preparation is duplicated, on CUs that would otherwise idle.
@@ -222,10 +223,10 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 char* const row = bb + (4 * tq + tt) * RSB + 8 * c4;
                 uint2 hi, lo;
                 if constexpr (!STATE_ONLY) {
-                    split4(rh, hi, lo);
+                    split4(rh, hi, lo, spc);
                     *reinterpret_cast<uint2*>(row + A_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_RL * ARR) = lo;
                 }
-                split4(kh, hi, lo);
+                split4(kh, hi, lo, spc);
                 *reinterpret_cast<uint2*>(row + A_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + A_KL * ARR) = lo;
             }
             WKV6_TP(3);
@@ -255,13 +256,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                     scm[q] = bt < x ? sc[q] : (bt == x ? cf : 0.f);
                 }
                 uint2 sh, sl;
-                split4(scm, sh, sl);
-                // stored [hi | lo][query token a = x][key token b] (32 B per (part, a)): a consumer lane takes the 8 key tokens of one
-                // half of one part with one 16-byte read -- the B fragment of the K-concatenated product (2) below; the two 16-byte
-                // halves of a row swap places for a >= 8 so that rows a and a + 8 (256 B apart) do not share banks in that read
-                char* const scw = bb + OFF_SC + x * 32 + 16 * ((g >> 1) ^ (x >> 3)) + 8 * (g & 1);
-                *reinterpret_cast<uint2*>(scw) = sh;
-                *reinterpret_cast<uint2*>(scw + 512) = sl;
+                split4(scm, sh, sl, spc);
+                *reinterpret_cast<uint4*>(bb + OFF_SC + lane * 16) = make_uint4(sh.x, sh.y, sl.x, sl.y);   // hi (4 key tokens) | lo: the lane's 8 k-slots
             }
             WKV6_TP(4);
         };
@@ -309,13 +305,12 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             St[it] = f4v{t4[0], t4[1], t4[2], t4[3]};
             asm volatile("" : "+v"(St[it]));                       // (an entry state still in flight is waited for here, not inside the loop)
         }
-        // Token contractions (K = the block's 16 tokens) run as ONE 16x16x32 MFMA per product pair: the hi and lo parts of the split
-        // operand are concatenated along K (k-slots 0..15 = hi of tokens 0..15, 16..31 = lo) against the exact operand repeated
-        // (V | V): lane group g supplies k-slots 8g..8g+7 = tokens 8 (g & 1) .. +7 of part g >> 1.  Both MFMA shapes cost 16 cycles
-        // (profiles/r05_issue_floor.md), so this halves the MFMAs of the state update and of the score product.
-        int troff = (8 * (g & 1) + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read of 4 of those tokens (+ 4 RSB: the other 4), natural columns (this wave's V tile)
-        int trow = (8 * (g & 1) + (x >> 2)) * RSB + 16 * (x & 3) + (g >> 1) * ((A_KL - A_KH) * ARR);   // ... tile-labelled columns (+ tile_tr(t)), Khat hi (g < 2) or lo
-        const int scoff = OFF_SC + 512 * (g >> 1) + 32 * x + 16 * ((g & 1) ^ (x >> 3));               // this lane's 16 bytes of the score fragment
+        // Token contractions (K = the block's 16 tokens) run as ONE 16x16x32 MFMA per product pair: lane group g supplies k-slots 8g .. 8g+7
+        // = (hi part, tokens 4g .. 4g+3 | lo part, the same tokens) of the split operand against the exact operand's four tokens twice
+        // (V | V) -- the very fragments the two 16x16x16 MFMAs took, concatenated in registers: no LDS read changes.  Both MFMA shapes
+        // cost 16 cycles (profiles/r05_issue_floor.md), so this halves the MFMAs of the state update and of the score product.
+        int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);      // transposed read, natural columns (this wave's V tile)
+        int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);      // transposed read, tile-labelled columns: + tile_tr(t)
         // (a null y -- the fused-epilogue forward of an inference call -- gets a zero-sized resource: its stores are dropped)
         const rsrc_t rs_y = make_rsrc(a.y ? gy_ : nullptr, (!STATE_ONLY && a.y && ntok > 0) ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u);
         const unsigned nst = ((unsigned)a.T + CKPT_TOK - 1) / CKPT_TOK;         // checkpoint slots of this (batch, head): 16 KB each
@@ -425,7 +420,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             // ~1300 cycles for the producers at the next barrier.  Consumer w starts a group w x 256 cycles late: the bursts no longer
             // collide (nor with the producers' stores), the delay comes out of the barrier wait.  Same box: forward -2.7 % (0.2198 ->
             // 0.2137 ms; 128 or 448 cycles per wave -0.8 / -1.5 %; staggering the producers too +1.2 ... 2 %: profiles/r05_stagger.txt).
-            for (int i_ = 0; i_ < wv; ++i_) __builtin_amdgcn_s_sleep(CONSUMER_STAGGER);
+            for (int i_ = 0; i_ < hwid; ++i_) __builtin_amdgcn_s_sleep(CONSUMER_STAGGER);   // (hwid: the consumer's index within its workgroup)
             if (staged && grp > 0) flush_y(grp - 1);
             if constexpr (ACC) acc_request(grp + 1, acc_nxt);     // (past the last group: past the end of the resource, reads zero)
 
@@ -472,13 +467,13 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 // ALL of the block's LDS operands are requested here, in one go, and the scheduler may not sink them: left to itself hipcc
                 // issues each read right in front of its use, and with two waves on a SIMD every one of the ~8 round trips of a block
                 // was exposed (the consumers' 5.7 k cycles per group were LDS latency, not issue: profiles/r04_fwd_prefetch.txt).
-                const b8v vf = __builtin_bit_cast(b8v, __builtin_shufflevector(tr_read(bb + A_V * ARR + troff + 32 * wv),
-                                                                               tr_read(bb + A_V * ARR + troff + 32 * wv + 4 * RSB), 0, 1, 2, 3, 4, 5, 6, 7));
+                const s4v vf4 = tr_read(bb + A_V * ARR + troff + 32 * wv);
+                const b8v vf = __builtin_bit_cast(b8v, __builtin_shufflevector(vf4, vf4, 0, 1, 2, 3, 4, 5, 6, 7));     // (V | V)
                 [[maybe_unused]] uint4 scp = {};
                 [[maybe_unused]] float4 pm0[2] = {}, pm1[2] = {};
                 [[maybe_unused]] b8v pzh[2] = {}, pzl[2] = {};
                 if constexpr (!STATE_ONLY) {
-                    scp = *reinterpret_cast<const uint4*>(bb + scoff);
+                    scp = *reinterpret_cast<const uint4*>(bb + OFF_SC + lane * 16);
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         pm0[s] = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g) * 4);
@@ -493,7 +488,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     pk8[it] = __builtin_bit_cast(b8v, __builtin_shufflevector(tr_read(bb + A_KH * ARR + trow + tile_tr(it)),
-                                                                              tr_read(bb + A_KH * ARR + trow + tile_tr(it) + 4 * RSB), 0, 1, 2, 3, 4, 5, 6, 7));
+                                                                              tr_read(bb + A_KL * ARR + trow + tile_tr(it)), 0, 1, 2, 3, 4, 5, 6, 7));
                     pd16[it] = *reinterpret_cast<const float4*>(bb + OFF_E16 + (tile_ch(it) + 8 * g) * 4);
                     pdm[it] = *reinterpret_cast<const float4*>(bb + OFF_E16M8 + (tile_ch(it) + 8 * g) * 4);
                 }
@@ -513,8 +508,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                         const float t1[4] = {St[2 * s + 1][0] * m1.x, St[2 * s + 1][1] * m1.y,
                                              St[2 * s + 1][2] * m1.z, St[2 * s + 1][3] * m1.w};
                         uint2 h0, l0, h1, l1;
-                        split4(t0, h0, l0);
-                        split4(t1, h1, l1);
+                        split4(t0, h0, l0, spc);
+                        split4(t1, h1, l1, spc);
                         const b8v s_hi = __builtin_bit_cast(b8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
                         const b8v s_lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
                         const b8v zh = pzh[s], zl = pzl[s];

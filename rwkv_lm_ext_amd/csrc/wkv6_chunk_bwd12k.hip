@@ -96,11 +96,11 @@ static_assert(BWD12K_LDS <= 160 * 1024, "LDS budget");
     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
 
 // split a C-layout tile pair (8 floats) into the hi / lo bf16x8 fragments of one k-step
-__device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4], b8v& hi, b8v& lo)
+__device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4], b8v& hi, b8v& lo, const SplitConst& spc)
 {
     uint2 h0, l0, h1, l1;
-    split4(t0, h0, l0);
-    split4(t1, h1, l1);
+    split4(t0, h0, l0, spc);
+    split4(t1, h1, l1, spc);
     hi = __builtin_bit_cast(b8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
     lo = __builtin_bit_cast(b8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
 }
@@ -126,6 +126,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][RBLK_BYTES] | [3][SBLK][KBLK_BYTES] | tiles | G operand
     const int tid = threadIdx.x, lane = tid & 63;
+    const SplitConst spc = split_const();
     const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = SPLIT ? (int)(slot & 1) : 0, bh = SPLIT ? (int)(slot >> 1) : (int)slot;
     const int wid = SPLIT ? (hwid < 4 ? hwid + 4 * part : hwid + 4) : hwid;
@@ -420,7 +421,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 const int tok = 2 * tq + tt;
                 char* const row = rb + tok * RSB + ch0 * 2;
                 uint2 hi, lo;
-                split4(rh, hi, lo);
+                split4(rh, hi, lo, spc);
                 *reinterpret_cast<uint2*>(row + R_RH * ARR) = hi; *reinterpret_cast<uint2*>(row + R_RL * ARR) = lo;
                 *reinterpret_cast<float4*>(rb + ROFF_FR + tok * FRS + ch0 * 4) = make_float4(fr[0], fr[1], fr[2], fr[3]);
             }
@@ -439,7 +440,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             if constexpr (HASK) {
                 char* const row = kb + (2 * tq + tt) * RSB + ch0 * 2;
                 uint2 hi, lo;
-                split4(kh, hi, lo);
+                split4(kh, hi, lo, spc);
                 *reinterpret_cast<uint2*>(row + K_KH * ARR) = hi; *reinterpret_cast<uint2*>(row + K_KL * ARR) = lo;
             }
         }
@@ -468,6 +469,11 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     const int x = lane & 15, g = lane >> 4;
     int troff = (4 * g + (x >> 2)) * RSB + 8 * (x & 3);          // transposed read, natural columns (own tile)
     int trow = (4 * g + (x >> 2)) * RSB + 16 * (x & 3);          // transposed read, tile-labelled columns: + tile_tr(t)
+    // Products of an exact operand (v, gy) with a split one (Khat, Rhat, the masked scores) over the block's 16 tokens run as ONE 16x16x32
+    // MFMA: lane group g supplies k-slots 8g .. 8g+7 = (hi part, tokens 4g .. 4g+3 | lo part, the same tokens) against the exact operand's
+    // four tokens twice -- the very fragments the two 16x16x16 MFMAs took, concatenated in registers (cat2), no LDS read changes.  Both
+    // shapes cost 16 cycles (profiles/r05_issue_floor.md): 18 of the 94 MFMAs per SIMD and stage fewer.
+    auto cat2 = [](s4v a_, s4v b_) { return __builtin_bit_cast(b8v, __builtin_shufflevector(a_, b_, 0, 1, 2, 3, 4, 5, 6, 7)); };
     // (explicit LDS address space: a volatile access through a generic pointer becomes a FLAT instruction whose wait drains the whole
     // vector-memory queue)
     typedef volatile int __attribute__((address_space(3))) lds_vint;
@@ -624,8 +630,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             for (int jt = 0; jt < 4; ++jt) {
                 const s4v vf = tr_read(kb + K_V * ARR + trow + tile_tr(jt));     // V[4g+e][tile_ch(jt) + 8(x>>2) + (x&3)]
                 f4v o = {0.f, 0.f, 0.f, 0.f};
-                o = mfma16(vf, khf, o);
-                o = mfma16(vf, klf, o);
+                o = mfma32(cat2(vf, vf), cat2(khf, klf), o);          // (V | V) (Khat_hi ; Khat_lo)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Sout[jt][q] = fmaf(e16, Sin[jt][q], e16m8 * o[q]);
             }
@@ -704,10 +709,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     dba[q] = o < x ? dA_ba[q] : 0.f;              // dA^T[b = o][a = x], strictly lower
                 }
                 uint2 th, tl;
-                split4(dab, th, tl);
+                split4(dab, th, tl, spc);
                 tile_store(XT_OFF + (2 * tb) * 1024, th, tl);
                 publish(TAG_DA + 2 * tb, grp + 1);
-                split4(dba, th, tl);
+                split4(dba, th, tl, spc);
                 tile_store(XT_OFF + (2 * tb + 1) * 1024, th, tl);
                 publish(TAG_DA + 2 * tb + 1, grp + 1);
             } else if constexpr (!SPLIT) {   // row waves 0 and 1: the masked score tile of block wv, for the column waves
@@ -733,7 +738,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     scm[q] = x < o ? sc[q] : (x == o ? cf[q] : 0.f);
                 }
                 uint2 th, tl;
-                split4(scm, th, tl);
+                split4(scm, th, tl, spc);
                 tile_store(XS_OFF + wv * 1024, th, tl);
                 publish(TAG_SC + wv, grp + 1);
             }
@@ -787,7 +792,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     b8v hi, lo;                                  // k-slot (s, g, e) <-> value channel 32s + 8g + e
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { t0[q] = ST[blk][2 * s][q]; t1[q] = ST[blk][2 * s + 1][q]; }
-                    split8(t0, t1, hi, lo);
+                    split8(t0, t1, hi, lo, spc);
                     accs = mfma32(hi, gyr[s], accs);
                     accs = mfma32(lo, gyr[s], accs);
                 }
@@ -866,8 +871,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     for (int jt = 0; jt < 4; ++jt) {             // [row j_local][col i_local = x]
                         const s4v gyf = tr_read(rb + R_GY * ARR + trow + tile_tr(jt));
                         f4v o = {0.f, 0.f, 0.f, 0.f};
-                        o = mfma16(gyf, rhf_w, o);
-                        o = mfma16(gyf, rlf_w, o);
+                        o = mfma32(cat2(gyf, gyf), cat2(rhf_w, rlf_w), o);
                         Oi[jt] = o;
                     }
 #pragma unroll
@@ -877,7 +881,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         b8v hi, lo;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { t0[q] = GI[2 * s][q] * e16m8x; t1[q] = GI[2 * s + 1][q] * e16m8x; }
-                        split8(t0, t1, hi, lo);
+                        split8(t0, t1, hi, lo, spc);
                         acck = mfma32(hi, vr, acck);
                         acck = mfma32(lo, vr, acck);
                     }
@@ -1009,7 +1013,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
                 t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
                 t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
-                split8(t0, t1, h[s], l[s]);
+                split8(t0, t1, h[s], l[s], spc);
             }
         };
         auto gop_write = [&](const b8v (&h)[2], const b8v (&l)[2]) {
@@ -1078,8 +1082,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     const s4v rhf = tr_read(rb + R_RH * ARR + trow + tile_tr(it));
                     const s4v rlf = tr_read(rb + R_RL * ARR + trow + tile_tr(it));
                     f4v o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma16(rhf, gyT, o);
-                    o = mfma16(rlf, gyT, o);
+                    o = mfma32(cat2(rhf, rlf), cat2(gyT, gyT), o);        // (Rhat_hi | Rhat_lo) (gy ; gy)
                     const float4 d16 = *reinterpret_cast<const float4*>(kb + KOFF_E16 + (tile_ch(it) + 8 * g) * 4);
                     const float4 d8 = *reinterpret_cast<const float4*>(rb + ROFF_E8 + (tile_ch(it) + 8 * g) * 4);
                     GJ[it][0] = fmaf(d16.x, GJ[it][0], d8.x * o[0]);
@@ -1115,7 +1118,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     scm[q] = x < o ? sc[q] : (x == o ? cf[q] : 0.f);
                 }
                 uint2 th, tl;
-                split4(scm, th, tl);
+                split4(scm, th, tl, spc);
                 tile_store(XS_OFF + wv * 1024, th, tl);
                 publish(TAG_SC + wv, grp + 1);
             }
@@ -1131,8 +1134,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #pragma unroll
             for (int blk = 0; blk < SBLK; ++blk) {
                 f4v acc = {0.f, 0.f, 0.f, 0.f};               // gv^T[j][b], first part: sum_a gy[a][j] A[a][b]
-                acc = mfma16(gyT_w[blk], sc_hi[blk], acc);
-                acc = mfma16(gyT_w[blk], sc_lo[blk], acc);
+                acc = mfma32(cat2(gyT_w[blk], gyT_w[blk]), cat2(sc_hi[blk], sc_lo[blk]), acc);     // (gy | gy) (A_hi ; A_lo)
                 accp[blk] = acc;
                 if constexpr (SPLIT) {
                     const char* const rb = rpart(grp, blk);
@@ -1141,8 +1143,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         const s4v rhf = tr_read(rb + R_RH * ARR + trow + tile_tr(it));
                         const s4v rlf = tr_read(rb + R_RL * ARR + trow + tile_tr(it));
                         f4v o = {0.f, 0.f, 0.f, 0.f};
-                        o = mfma16(rhf, gyT_w[blk], o);
-                        o = mfma16(rlf, gyT_w[blk], o);
+                        o = mfma32(cat2(rhf, rlf), cat2(gyT_w[blk], gyT_w[blk]), o);
                         Og[blk][it] = o;
                     }
                 }
@@ -1165,7 +1166,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                         t0[0] = GJ[2 * s][0] * m0.x; t0[1] = GJ[2 * s][1] * m0.y; t0[2] = GJ[2 * s][2] * m0.z; t0[3] = GJ[2 * s][3] * m0.w;
                         t1[0] = GJ[2 * s + 1][0] * m1.x; t1[1] = GJ[2 * s + 1][1] * m1.y;
                         t1[2] = GJ[2 * s + 1][2] * m1.z; t1[3] = GJ[2 * s + 1][3] * m1.w;
-                        split8(t0, t1, gh[blk][s], gl[blk][s]);
+                        split8(t0, t1, gh[blk][s], gl[blk][s], spc);
                     }
                     acc = mfma32(gh[blk][s], kh, acc);       // k-slot (s, g, e) <-> key channel 32s + 8g + e
                     acc = mfma32(gh[blk][s], kl, acc);
@@ -1373,6 +1374,9 @@ hipError_t launch_chunk_bwd_bi(const ScanArgs& a1_, const ScanArgs& a2_, int* sl
     const int n = bi_slots(a1_.B * a1_.H);
     if (slots) *slots = n;
     if (!n || !a1_.ckpt || !a2_.ckpt || a1_.g_in || a1_.rc_in) return hipErrorNotSupported;
+    // (raw bf16 decay only -- the autograd layer's path.  The fp32-ew instantiation of the two-body kernel reloads two spilled registers
+    // inside its stage loops; the reference-signature symbols, which pass fp32 ew, keep the two launches.)
+    if (a1_.wkind != 1) return hipErrorNotSupported;
     if (a1_.wkind != 1 && ((long)a1_.T + 64) * a1_.C >= (1L << 30)) return hipErrorInvalidValue;
     ScanArgs a1 = a1_, a2 = a2_;
     for (ScanArgs* a : {&a1, &a2}) {
@@ -1388,14 +1392,9 @@ hipError_t launch_chunk_bwd_bi(const ScanArgs& a1_, const ScanArgs& a2_, int* sl
 #endif
     }
     constexpr size_t lds = BWD12K_LDS;
-    static LdsAttrOnce attr_raw, attr_ew;
-    if (a1.wkind) {
-        if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_bwd12k_bi_kernel<true>), lds)) return e;
-        hipLaunchKernelGGL((chunk_bwd12k_bi_kernel<true>), dim3(n), dim3(768), lds, st, a1, a2.ckpt);
-    } else {
-        if (hipError_t e = attr_ew.ensure(reinterpret_cast<const void*>(chunk_bwd12k_bi_kernel<false>), lds)) return e;
-        hipLaunchKernelGGL((chunk_bwd12k_bi_kernel<false>), dim3(n), dim3(768), lds, st, a1, a2.ckpt);
-    }
+    static LdsAttrOnce attr_raw;
+    if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_bwd12k_bi_kernel<true>), lds)) return e;
+    hipLaunchKernelGGL((chunk_bwd12k_bi_kernel<true>), dim3(n), dim3(768), lds, st, a1, a2.ckpt);
     return hipGetLastError();
 }
 

@@ -416,7 +416,7 @@ def bi_new_workspace(B, T, C, H, device):
 
 def bi_new_kept(B, T, C, H, device):
     """The part of the wkv6_bi workspace that has to live from the forward to the backward (row lengths, order, the state
-    checkpoints of both scans: 8 B per token-channel at 64-token checkpoint spacing); passed as `ws`, the fp32 side buffers
+    checkpoints of both scans: 2 x 4 B per token-channel at 64-token checkpoint spacing); passed as `ws`, the fp32 side buffers
     (4 B per token-channel in the forward, 16 B in the backward) become per-call scratch of the library."""
     return torch.empty(_lib.load().wkv6bi_kept_bytes(B, T, C, H), dtype=torch.uint8, device=device)
 

@@ -29,7 +29,7 @@ def test_committed_pmc_figures_are_consistent():
 
 def test_committed_bench_lines_carry_the_contract_fields():
     root = os.path.dirname(os.path.abspath(bench.__file__))
-    for name in ("r04_bench_final.json", "r04_bench_bi.json", "r04_bench_infctx.json"):
+    for name in ("r05_bench_final.json", "r05_bench_bi.json", "r05_bench_infctx.json", "r04_bench_final.json"):
         with open(os.path.join(root, "profiles", name)) as f:
             d = json.loads(f.read())
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",

@@ -42,7 +42,7 @@ out = {"command": "tools/collect_profiles.sh (rocprofv3 --kernel-trace --pmc <gr
 # instantiation with the most dispatches, i.e. the one the bench loop launches
 best = {}
 for k, cs in acc.items():
-    short = next((n for n in ("chunk_fwd_kernel", "chunk_bwd12k_kernel", "chunk_bwd12_kernel", "chunk_bwd64_kernel") if n in k), None)
+    short = next((n for n in ("chunk_fwd_kernel", "chunk_bwd12k_kernel") if n in k), None)
     if short is None:
         continue
     n = max(len(v) for v in cs.values())

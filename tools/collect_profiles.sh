@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline block refers to.  Run on the GPU box from the repo root:
 #     bash tools/collect_profiles.sh gpurun_out/prof
-# then, back in the container:  python tools/aggregate_profiles.py gpurun_out/prof profiles/r04_final
+# then, back in the container:  python tools/aggregate_profiles.py gpurun_out/prof profiles/r05_final
 # (kernel-trace/stats and every --pmc group are separate runs; no sys/hip trace is combined with --pmc).
 set -e -o pipefail
 OUT=${1:-gpurun_out/prof}
@@ -23,6 +23,6 @@ for wl in bi infctx; do
     python3 $ROOT/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu > "$ROOT/$OUT/bench_$wl.json" 2> /dev/null
 done
 python3 $ROOT/bench.py --workload prefill --steps 20 --warmup 5 --no-cpu > "$ROOT/$OUT/bench_prefill.json" 2> /dev/null
-WKV6_BWD=64 python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu --traffic none > "$ROOT/$OUT/bench_wkv6_bwd64.json" 2> /dev/null   # the two-level experiment
+python3 $ROOT/bench.py --workload dp_lora --steps 10 --warmup 3 > "$ROOT/$OUT/bench_dp_lora.json" 2> "$ROOT/$OUT/bench_dp_lora.err" || echo "dp_lora failed"   # configs[3], 24 layers, one GPU (DDP over a one-rank RCCL group)
 python3 $ROOT/bench.py --steps 100 --warmup 20 > "$ROOT/$OUT/bench_wkv6.json" 2> "$ROOT/$OUT/bench_wkv6.err"           # traffic measured live
 echo done

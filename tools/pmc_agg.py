@@ -11,7 +11,7 @@ for f in glob.glob(sys.argv[1] + "/pmc*/**/*counter_collection.csv", recursive=T
         k = row["Kernel_Name"]
         if "chunk" not in k:
             continue
-        k = "bwd64" if "bwd64" in k else ("bwd12" if "bwd12" in k else ("fwd" if "chunk_fwd" in k else k[:40]))
+        k = "bwd12" if "bwd12" in k else ("fwd" if "chunk_fwd" in k else k[:40])
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
     print(k)

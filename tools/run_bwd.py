@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run the forward and the backward of the operator a few times at config 2 (profiling driver for rocprofv3):
-    WKV6_BWD=64 python tools/run_bwd.py [iters]"""
+    python tools/run_bwd.py [iters]"""
 import os
 import sys
 
