@@ -61,7 +61,7 @@ constexpr int YS_BYTES = GRP * YRS;
 // The kernel proper is a device function of (arguments, workgroup slot): chunk_fwd_kernel runs it on its one argument block,
 // chunk_fwd_pair_kernel (the two WKV problems of a bidirectional composition in ONE launch) on one of two.
 // CLK: the in-run clock probe (wkv6_set_clock_buffer) is compiled into the plain kernel only.
-template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false, bool CLK = false>
+template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN, bool AFF, bool CLK = false>
 __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot, const unsigned sslot = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2] | float [4 consumers][1024] | y rows [2][64][YRS]
@@ -85,7 +85,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const int ngrp = (ntok + GRP - 1) / GRP;
-    const RevMap tokmap = make_revmap(a, b, ntok);
+    const TokAddr<AFF> tok(a, b, ntok);                           // token addressing (wkv6_scan.h): AFF = no per-tensor reversal map
+    const int C_ = a.C;
 #ifdef WKV6_STAMP
     unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
 #endif
@@ -109,11 +110,13 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         const rsrc_t rs_v = make_rsrc(gv_, ntok > 0 ? span * 2 + 128 : 0);
         const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, ntok > 0 ? span * 2 + 128 : 0)
                                   : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? span * 4 + 256 : 0);
+        const int lp_in[4] = {tok.lane(wv * BLK + 4 * tq, 4 * c4, C_), tok.lane(wv * BLK + 4 * tq + 1, 4 * c4, C_),
+                              tok.lane(wv * BLK + 4 * tq + 2, 4 * c4, C_), tok.lane(wv * BLK + 4 * tq + 3, 4 * c4, C_)};
         auto load_quad = [&](int grp, int tt) {                       // token quad tt of the wave's block: one instruction per tensor
             {
-                const int p = grp * GRP + wv * BLK + 4 * tq + tt;
-                const unsigned ir = (unsigned)(tokmap(p, REV_R) * a.C + 4 * c4), ik = (unsigned)(tokmap(p, REV_K) * a.C + 4 * c4);
-                const unsigned iv = (unsigned)(tokmap(p, REV_V) * a.C + 4 * c4), iw = (unsigned)(tokmap(p, REV_W) * a.C + 4 * c4);
+                const int pl = wv * BLK + 4 * tq + tt;
+                const unsigned ir = tok.off(grp * GRP, pl, 4 * c4, C_, REV_R, lp_in[tt]), ik = tok.off(grp * GRP, pl, 4 * c4, C_, REV_K, lp_in[tt]);
+                const unsigned iv = tok.off(grp * GRP, pl, 4 * c4, C_, REV_V, lp_in[tt]), iw = tok.off(grp * GRP, pl, 4 * c4, C_, REV_W, lp_in[tt]);
                 if constexpr (!STATE_ONLY) pr[tt] = buf_load8(rs_r, ir * 2);
                 else pr[tt] = make_uint2(0u, 0u);
                 pk[tt] = buf_load8(rs_k, ik * 2);
@@ -183,7 +186,9 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             WKV6_TP(0);
             // (the sixteen loads of the next group: ~2000 cycles of issue for the wave wherever they are placed -- behind the whole
             // preparation, here, or four at a time inside the loop above (+6 %): the four producers' 32 KB per group are a third of
-            // what the CU's vector-memory pipe moves in a group at ~10 B per cycle, profiles/r05_fwd_prep_stamps.txt)
+            // what the CU's vector-memory pipe moves in a group at ~10 B per cycle, profiles/r05_fwd_prep_stamps.txt; v moved by the
+            // consumer waves instead -- which wait ~1800 cycles at the group barrier -- as two 16-byte-per-lane loads a group ahead: +3 %,
+            // profiles/r05_fwd_v_by_consumers.txt)
             if (next >= 0) load_group(next);
             WKV6_TP(1);
             float pre[4], c8[4], c16[4];
@@ -331,13 +336,15 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         const unsigned ych = a.side_compact ? 16u * (unsigned)hwid : 16u * (unsigned)wv;             // this consumer's channels in a side row
         const rsrc_t rs_yf = make_rsrc(a.y_f32 ? a.y_f32 + (a.side_compact ? (long)sslot * a.T * HEAD : base) : nullptr,
                                        (a.y_f32 && !STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * ystr * 4u + 256u : 0u);
+        // lane parts of this consumer's result tile (token x of a block, channels 16 wv + 4 g ..) in y and in the fp32 side buffer
+        const int lp_y = tok.lane(x, 16 * wv + 4 * g, C_), lp_ys = tok.lane(x, (int)ych + 4 * g, (int)ystr);
         [[maybe_unused]] uint4 acc_cur[NBLK] = {}, acc_nxt[NBLK] = {};
         auto acc_request = [&](int grp_, uint4 (&dst)[NBLK]) {
 #pragma unroll
             for (int blk = 0; blk < NBLK; ++blk) {
-                const unsigned idx = (unsigned)(tokmap(grp_ * GRP + blk * BLK + x, REV_Y) * a.C + 16 * wv + 4 * g);
+                const unsigned idx = tok.off(grp_ * GRP + blk * BLK, x, 16 * wv + 4 * g, C_, REV_Y, lp_y);
                 if (a.y_f32) {
-                    const float4 t = buf_load16f(rs_yf, ((unsigned)tokmap(grp_ * GRP + blk * BLK + x, REV_Y) * ystr + ych + 4u * g) * 4u);
+                    const float4 t = buf_load16f(rs_yf, tok.off(grp_ * GRP + blk * BLK, x, (int)ych + 4 * g, (int)ystr, REV_Y, lp_ys) * 4u);
                     dst[blk] = make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w));
                 } else {
                     const uint2 t = buf_load8(rs_y, idx * 2u);
@@ -374,7 +381,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             for (int i = 0; i < 2; ++i) {
                 const int row = (GRP >> (ylsh - 1)) * hwid + (64 >> ylsh) * i + (lane >> ylsh), chunk = lane & ((1 << ylsh) - 1);
                 const uint4 v = *reinterpret_cast<const uint4*>(ys + (grp_ & 1) * YS_BYTES + row * YRS + 16 * chunk);
-                const unsigned off = (unsigned)(tokmap(grp_ * GRP + row, REV_Y) * a.C + 32 * part + 8 * chunk) * 2u;
+                const unsigned off = tok.off(grp_ * GRP, row, 32 * part + 8 * chunk, C_, REV_Y, tok.lane(row, 32 * part + 8 * chunk, C_)) * 2u;
                 buf_store16(rs_y, off, v);                         // (tokens past the end: dropped by the bounds check)
             }
         };
@@ -406,7 +413,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 buf_store8(rs_out, gn_off[blk], make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
                 const int p = grp * GRP + blk * BLK + x;
                 if (a.gn_stats && wv == 0 && g == 0 && p < ntok) {
-                    float* const sp = a.gn_stats + (((long)b * a.T + tokmap(p, REV_Y)) * a.H + h) * 2;
+                    float* const sp = a.gn_stats + (((long)b * a.T + tok.token(p, REV_Y)) * a.H + h) * 2;
                     sp[0] = mean; sp[1] = rstd;
                 }
             }
@@ -521,7 +528,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                         const int p = grp * GRP + blk * BLK + x;
                         float o[4] = {yt[0], yt[1], yt[2], yt[3]};
                         if (!ACC && !a.y_f32) {                          // plain store: tokens past the end are dropped by the hardware
-                            const unsigned off = (unsigned)(tokmap(p, REV_Y) * a.C + 16 * wv + 4 * g) * 2u;
+                            const unsigned off = tok.off(grp * GRP + blk * BLK, x, 16 * wv + 4 * g, C_, REV_Y, lp_y) * 2u;
                             const uint2 yb = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
                             if constexpr (GN) buf_store8(rs_y, off, yb);   // (a null y: zero-sized resource, the store is dropped)
                             else stage_y(grp, blk, yb);
@@ -539,7 +546,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                             }
                         } else {
                             if constexpr (ACC) acc_add(acc_cur[blk], o);          // requested a group ago
-                            if (!ACC && a.y_f32) buf_store16f(rs_yf, ((unsigned)tokmap(p, REV_Y) * ystr + ych + 4u * g) * 4u, o);
+                            if (!ACC && a.y_f32) buf_store16f(rs_yf, tok.off(grp * GRP + blk * BLK, x, (int)ych + 4 * g, (int)ystr, REV_Y, lp_ys) * 4u, o);
                             else stage_y(grp, blk, make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])));
                         }
                     }
@@ -601,10 +608,10 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
     }
 }
 
-template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false>
+template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN, bool AFF>
 __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 {
-    chunk_fwd_body<W_RAW, STATE_ONLY, ACC, GN, !STATE_ONLY && !ACC && !GN>(a, blockIdx.x);
+    chunk_fwd_body<W_RAW, STATE_ONLY, ACC, GN, AFF, !STATE_ONLY && !ACC && !GN>(a, blockIdx.x);
 }
 
 // Two problems of the same shape in one grid of 2 B H workgroups: slots [0, B H) serve a0, the rest a1 (src/model_bi.py:331-348,
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_pair_kernel(const ScanArgs a0, 
 {
     const unsigned n = (unsigned)(a0.B * a0.H);
     const bool second = blockIdx.x >= n;                      // workgroup-uniform: the argument block is read through one of two
-    chunk_fwd_body<W_RAW, false, false, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);   // kernarg addresses
+    chunk_fwd_body<W_RAW, false, false, false, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);   // kernarg addresses; per-tensor reversal maps: general addressing
 }
 
 // Both halves of wkv6_bi in one persistent launch (cuda/wkv6_bi_cuda.cu:363-368 is one launch too): workgroup slot s walks the rows
@@ -631,25 +638,33 @@ __global__ __launch_bounds__(512) void chunk_fwd_bi_kernel(const ScanArgs a1, fl
     for (unsigned it = 0; it * gridDim.x < n; ++it) {
         const unsigned row = it * gridDim.x + ((it & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x);
         if (row >= n) continue;                                     // (the last round may be short; workgroup-uniform)
-        chunk_fwd_body<W_RAW, false, false>(a1, row, blockIdx.x);
+        chunk_fwd_body<W_RAW, false, false, false, true>(a1, row, blockIdx.x);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         ScanArgs a2 = a1;
         a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.ckpt = ckpt2;
-        chunk_fwd_body<W_RAW, false, true>(a2, row, blockIdx.x);
+        chunk_fwd_body<W_RAW, false, true, false, true>(a2, row, blockIdx.x);
         __syncthreads();
     }
 }
 
-template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
+template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN, bool AFF> hipError_t launch_fwd_variant2(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = 2 * (size_t)GRP_BYTES + (GN ? 4096 : 0) + CKX_BYTES + 2 * YS_BYTES;
     static LdsAttrOnce attr;                   // per instantiation and device
-    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), lds)) return e;
-    if (a.split) hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), dim3(2 * a.B * a.H), dim3(384), lds, st, a);
-    else hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN>), dim3(a.B * a.H), dim3(512), lds, st, a);
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN, AFF>), lds)) return e;
+    if (a.split) hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN, AFF>), dim3(2 * a.B * a.H), dim3(384), lds, st, a);
+    else hipLaunchKernelGGL((chunk_fwd_kernel<W_RAW, STATE_ONLY, ACC, GN, AFF>), dim3(a.B * a.H), dim3(512), lds, st, a);
     return hipGetLastError();
+}
+// per-tensor reversal maps (a.rev_n: the compositions' *_rev_ex calls and their state passes) take the general token addressing; the
+// accumulating half of wkv6_bi and the GroupNorm epilogue never carry one
+template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN = false> hipError_t launch_fwd_variant(const ScanArgs& a, hipStream_t st)
+{
+    if constexpr (!ACC && !GN) { if (a.rev_n) return launch_fwd_variant2<W_RAW, STATE_ONLY, false, false, false>(a, st); }
+    else if (a.rev_n) return hipErrorNotSupported;
+    return launch_fwd_variant2<W_RAW, STATE_ONLY, ACC, GN, true>(a, st);
 }
 
 }  // namespace

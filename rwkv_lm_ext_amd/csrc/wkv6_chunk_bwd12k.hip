@@ -121,7 +121,7 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 // tiles.  Every wave does the same arithmetic as in the one-workgroup launch: the outputs are bit-identical.
 // CLK: the in-run clock probe (wkv6_set_clock_buffer) is compiled into the plain kernel only (it costs ~6 SGPRs, which the wkv6_bi
 // and pair instantiations do not have).
-template <bool W_RAW, int GEN, bool SPLIT, bool CLK = false>
+template <bool W_RAW, int GEN, bool SPLIT, bool AFF, bool CLK = false>
 __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot, const unsigned sslot = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][RBLK_BYTES] | [3][SBLK][KBLK_BYTES] | tiles | G operand
@@ -146,7 +146,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw) + base;
     int ntok = a.T;
     if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
-    const RevMap tokmap = make_revmap(a, b, ntok);
+    const TokAddr<AFF> tok(a, b, ntok);                       // token addressing (wkv6_scan.h): AFF = no per-tensor reversal map
+    const int C_ = a.C;
     // buffer resources over this row's first ntok tokens (wkv6_common.h): loads past the end return 0, stores are dropped
     const unsigned nbytes = ntok > 0 ? (unsigned)(ntok - 1) * a.C * 2u + 128u : 0u;
     const rsrc_t rs_gr = make_rsrc(ogr, nbytes), rs_gk = make_rsrc(ogk, nbytes), rs_gv = make_rsrc(ogv, nbytes), rs_gw = make_rsrc(ogw, nbytes);
@@ -162,9 +163,13 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                                make_rsrc(GEN && a.g_f32[1] ? a.g_f32[1] + sbase : nullptr, GEN && a.g_f32[1] ? nbytes4 : 0u),
                                make_rsrc(GEN && a.g_f32[2] ? a.g_f32[2] + sbase : nullptr, GEN && a.g_f32[2] ? nbytes4 : 0u),
                                make_rsrc(GEN && a.g_f32[3] ? a.g_f32[3] + sbase : nullptr, GEN && a.g_f32[3] ? nbytes4 : 0u)};
-    auto fetch_old = [&](int which, const rsrc_t& rs, int p, unsigned bit, int ch, float (&old)[4]) {
+    // (lane parts of the offsets of this wave's result tile: token x_ of a block, channels 16 wv + 4 g_ .. in the side buffers; the merged
+    // two-block rows of `put` in the outputs)
+    const int lp_side = tok.lane(lane & 15, 16 * wv + 4 * (lane >> 4), (int)sstr);
+    const int lp_put = tok.lane((((lane >> 4) & 1) ? 0 : BLK) + (lane & 15), 16 * wv + 8 * (lane >> 5), C_);
+    auto fetch_old = [&](int which, const rsrc_t& rs, int pu, unsigned bit, float (&old)[4]) {     // pu: first position of the block
         if constexpr (GEN == 2) {
-            const unsigned idx = (unsigned)tokmap(p, bit) * sstr + (unsigned)ch;
+            const unsigned idx = tok.off(pu, lane & 15, 16 * wv + 4 * (lane >> 4), (int)sstr, bit, lp_side);
             const float4 t = buf_load16f(rs_side[which], idx * 4u);   // (the halves of wkv6_bi always meet in the fp32 side buffers: checked at launch)
             old[0] = t.x; old[1] = t.y; old[2] = t.z; old[3] = t.w;
         }
@@ -205,20 +210,21 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     auto put = [&](int which, const rsrc_t& rs, int stg, int blk, unsigned bit, uint2 v) {   // this lane: token x_ of the block, channels 16 wv + 4 g_ .. + 3
         if constexpr (GEN == 1) return;                            // (went to the fp32 side buffer in emit)
 #if WKV6_STORE_MODE == 0
-        buf_store8(rs, (unsigned)(tokmap(stg * STG + blk * BLK + x_, bit) * a.C + 16 * wv + 4 * g_) * 2u, v);
+        buf_store8(rs, tok.off(stg * STG + blk * BLK, x_, 16 * wv + 4 * g_, C_, bit, tok.lane(x_, 16 * wv + 4 * g_, C_)) * 2u, v);
 #else
         if (blk == SBLK - 1) { held_st[which] = v; return; }      // (the stage's blocks are walked 1, 0)
         const auto sx = __builtin_amdgcn_permlane16_swap(held_st[which].x, v.x, false, false);
         const auto sy = __builtin_amdgcn_permlane16_swap(held_st[which].y, v.y, false, false);
-        const int p = stg * STG + ((g_ & 1) ? 0 : BLK) + x_;         // even lane rows: block 1's token, odd rows: block 0's
-        buf_store16(rs, (unsigned)(tokmap(p, bit) * a.C + 16 * wv + 8 * (g_ >> 1)) * 2u, make_uint4(sx[0], sy[0], sx[1], sy[1]));
+        // even lane rows: block 1's token, odd rows: block 0's
+        buf_store16(rs, tok.off(stg * STG, ((g_ & 1) ? 0 : BLK) + x_, 16 * wv + 8 * (g_ >> 1), C_, bit, lp_put) * 2u,
+                    make_uint4(sx[0], sy[0], sx[1], sy[1]));
 #endif
     };
     // the result of one block: fp32 side buffer (first half of wkv6_bi: 64-byte pieces, 16 bytes per lane as they are) or the packed
     // bf16 quad for `put`
     auto emit = [&](int which, int stg, int blk, unsigned bit, float (&o)[4], const float (&old)[4]) -> uint2 {
         if constexpr (GEN == 1) {
-            const unsigned idx = (unsigned)tokmap(stg * STG + blk * BLK + x_, bit) * sstr + (unsigned)(16 * wv + 4 * g_);
+            const unsigned idx = tok.off(stg * STG + blk * BLK, x_, 16 * wv + 4 * g_, (int)sstr, bit, lp_side);
             buf_store16f(rs_side[which], idx * 4u, o);
             return make_uint2(0u, 0u);
         }
@@ -260,21 +266,21 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     const rsrc_t rs_r = make_rsrc(gr_, nbytes), rs_k = make_rsrc(gk_, nbytes), rs_v = make_rsrc(gv_, nbytes), rs_g = make_rsrc(ggy, nbytes);
     const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, nbytes)
                               : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? (unsigned)(ntok - 1) * a.C * 4u + 256u : 0u);
+    const int lp_in[2] = {tok.lane(pb * BLK + 2 * tq, ch0, C_), tok.lane(pb * BLK + 2 * tq + 1, ch0, C_)};
     auto load_r = [&](int stg) {       // tokens past the end load zeros
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const int p = stg * STG + pb * BLK + 2 * tq + tt;
-            nr[tt] = buf_load8(rs_r, (unsigned)(tokmap(p, REV_R) * a.C + ch0) * 2u);
-            if constexpr (SPLIT) ng[tt] = buf_load8(rs_g, (unsigned)(tokmap(p, REV_Y) * a.C + ch0) * 2u);
+            nr[tt] = buf_load8(rs_r, tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_R, lp_in[tt]) * 2u);
+            if constexpr (SPLIT) ng[tt] = buf_load8(rs_g, tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_Y, lp_in[tt]) * 2u);
         }
     };
     auto load_kw = [&](int stg) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const int p = stg * STG + pb * BLK + 2 * tq + tt;
-            const unsigned ik = (unsigned)(tokmap(p, REV_K) * a.C + ch0), iw = (unsigned)(tokmap(p, REV_W) * a.C + ch0);
+            const int pl = pb * BLK + 2 * tq + tt;
+            const unsigned ik = tok.off(stg * STG, pl, ch0, C_, REV_K, lp_in[tt]), iw = tok.off(stg * STG, pl, ch0, C_, REV_W, lp_in[tt]);
             nk[tt] = buf_load8(rs_k, ik * 2u);
-            if constexpr (SPLIT) nv[tt] = buf_load8(rs_v, (unsigned)(tokmap(p, REV_V) * a.C + ch0) * 2u);
+            if constexpr (SPLIT) nv[tt] = buf_load8(rs_v, tok.off(stg * STG, pl, ch0, C_, REV_V, lp_in[tt]) * 2u);
             if constexpr (W_RAW) nw[tt] = buf_load8(rs_w, iw * 2u);
             else ne[tt] = buf_load16f(rs_w, iw * 4u);
         }
@@ -501,39 +507,33 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #else
 #define WKV6_SPIN_GUARD(idx, tag, seen) do { } while (0)
 #endif
-    // readers poll two / four adjacent tags with one LDS round trip (a poll costs an LDS latency plus a drain of the wave's LDS queue)
-    auto await2 = [&](int idx, int tag) {
+    // readers poll two / four adjacent tags with one LDS round trip (a poll costs an LDS latency plus a drain of the wave's LDS queue):
+    // lane l reads tag idx + (l & 3) (or & 1) -- one dword per lane, the same four addresses wave-wide, a broadcast -- and the wave votes:
+    // one compare into a lane mask and a scalar test per poll (round 5; a 16-byte read per lane needed 4 xor + 3 or + a
+    // v_readfirstlane: 8 vector issue slots per poll, ~56 of the 1066 per SIMD and stage)
+    const int lane_tag4 = (lane & 3) * 4, lane_tag2 = (lane & 1) * 4;
+    auto tags_differ = [&](unsigned f, int tag) { return __builtin_amdgcn_ballot_w64(f != (unsigned)tag) != 0; };
+    auto await_n = [&](int idx, int tag, int lane_off) {
         [[maybe_unused]] unsigned spins = 0;
         WKV6_T5(1, tp0);
         for (;;) {
-            const v2u_t f = *(volatile v2u_t __attribute__((address_space(3)))*)xflag_at(idx);
-            if (__builtin_amdgcn_readfirstlane((int)((f.x ^ (unsigned)tag) | (f.y ^ (unsigned)tag))) == 0) break;
-            WKV6_SPIN_GUARD(idx, tag, f.x);
+            const unsigned f = (unsigned)*(lds_vint*)((unsigned char __attribute__((address_space(3)))*)xflag_at(idx) + lane_off);
+            if (!tags_differ(f, tag)) break;
+            WKV6_SPIN_GUARD(idx, tag, f);
             __builtin_amdgcn_s_sleep(1);
         }
         WKV6_T5(1, tp1); WKV6_ACC5(1, tp1, tp0); WKV6_ACCP(idx, tp1, tp0);
     };
-    auto await4 = [&](int idx, int tag) {
-        [[maybe_unused]] unsigned spins = 0;
-        WKV6_T5(1, tp0);
-        for (;;) {
-            const v4u_t f = *(lds_vv4u*)xflag_at(idx);
-            const unsigned t = (unsigned)tag;
-            if (__builtin_amdgcn_readfirstlane((int)((f.x ^ t) | (f.y ^ t) | (f.z ^ t) | (f.w ^ t))) == 0) break;
-            WKV6_SPIN_GUARD(idx, tag, f.x);
-            __builtin_amdgcn_s_sleep(1);
-        }
-        WKV6_T5(1, tp1); WKV6_ACC5(1, tp1, tp0); WKV6_ACCP(idx, tp1, tp0);
-    };
+    auto await2 = [&](int idx, int tag) { await_n(idx, tag, lane_tag2); };
+    auto await4 = [&](int idx, int tag) { await_n(idx, tag, lane_tag4); };
     // A poll whose tag is already there still costs an LDS round trip with the wave's LDS queue drained.  Where the schedule allows, the
     // tag read is issued ahead (peek4) with independent work behind it and only examined later (settle4): satisfied -- the usual case --
     // it costs a compare; otherwise the ordinary poll takes over.  Readers of the handed-over data are volatile accesses or get
     // their address through an asm volatile behind settle4, as after await4: the LDS serves a wave's requests in order.
-    auto peek4 = [&](int idx) -> v4u_t { return *(lds_vv4u*)xflag_at(idx); };
-    auto settle4 = [&](int idx, int tag, const v4u_t f) {
-        const unsigned t = (unsigned)tag;
-        if (__builtin_amdgcn_readfirstlane((int)((f.x ^ t) | (f.y ^ t) | (f.z ^ t) | (f.w ^ t))) != 0) await4(idx, tag);
+    auto peek4 = [&](int idx) -> unsigned {
+        return (unsigned)*(lds_vint*)((unsigned char __attribute__((address_space(3)))*)xflag_at(idx) + lane_tag4);
     };
+    auto settle4 = [&](int idx, int tag, const unsigned f) { if (tags_differ(f, tag)) await4(idx, tag); };
     auto tile_store = [&](int off, uint2 hi, uint2 lo) {
         *(lds_vv4u*)(smem + off + lane * 16) = v4u_t{hi.x, hi.y, lo.x, lo.y};
     };
@@ -686,7 +686,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             // (second half of wkv6_bi: the first half's gr of both blocks, requested a pre-phase ahead of the sums they meet)
             float old_gr[SBLK][4] = {}, old_gk[SBLK][4] = {}, old_gw[SBLK][4] = {};
 #pragma unroll
-            for (int blk = SBLK - 1; blk >= 0; --blk) fetch_old(0, rs_gr, grp * STG + blk * BLK + x, REV_R, 16 * wv + 4 * g, old_gr[blk]);
+            for (int blk = SBLK - 1; blk >= 0; --blk) fetch_old(0, rs_gr, grp * STG + blk * BLK, REV_R, old_gr[blk]);
             // then, so that it is there long before the others ask for it:
             if (wv >= 2) {   // this wave's dA tiles of the stage: block wv - 2, both orientations (tile 2 blk: dA[a][b], lane col b; 2 blk + 1:
                              // dA^T[b][a], lane col a) from one pair of operand reads.  Row waves 0 and 1 make the score tiles instead.
@@ -752,10 +752,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 advance(kpart(grp - 1, 1), ST[0], ST[0]);
             }
             // ---- rebuild the entry state of block 1
-            [[maybe_unused]] v4u_t pk_gc = {};
+            [[maybe_unused]] unsigned pk_gc = 0;
 #pragma unroll
             for (int blk = 0; blk < SBLK - 1; ++blk) advance(kpart(grp, blk), ST[blk], ST[blk + 1]);
-            const v4u_t pk_da = peek4(TAG_DA);                    // (examined where the pre-phase starts)
+            const unsigned pk_da = peek4(TAG_DA);                    // (examined where the pre-phase starts)
             WKV6_T(ts2);
             // ---- pre-phase: everything that does not depend on G (blocks past the end of the sequence are neutral):
             //      dA, the whole gr path (it needs only the forward states) and the Rhat.dA part of gk.
@@ -831,8 +831,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             // (... and its gk, gw, a chain ahead)
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) {
-                fetch_old(1, rs_gk, grp * STG + blk * BLK + x, REV_K, 16 * wv + 4 * g, old_gk[blk]);
-                fetch_old(3, rs_gw, grp * STG + blk * BLK + x, REV_W, 16 * wv + 4 * g, old_gw[blk]);
+                fetch_old(1, rs_gk, grp * STG + blk * BLK, REV_K, old_gk[blk]);
+                fetch_old(3, rs_gw, grp * STG + blk * BLK, REV_W, old_gw[blk]);
             }
             WKV6_T5(2, tp0);
             // The even stage of a pair enters with the pair's checkpoint itself -- which its odd stage left untouched in CK (the rebuild
@@ -967,18 +967,17 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         // iteration until its gy arrives).  lane = (token tl, channels 4cl .. 4cl+3); requested at the head of a stage, written at its end.
         const int tl = lane >> 4, cl = lane & 15;
         uint2 cv[SBLK], cg[SBLK], cvp[SBLK];
+        const int lp_vg = tok.lane(4 * wv + tl, 4 * cl, C_);
         auto load_v = [&](int stg) {
 #pragma unroll
             for (int blk = 0; blk < SBLK; ++blk) {
-                const int p = stg * STG + blk * BLK + 4 * wv + tl;
-                cv[blk] = buf_load8(rs_v, (unsigned)(tokmap(p, REV_V) * a.C + 4 * cl) * 2u);
+                cv[blk] = buf_load8(rs_v, tok.off(stg * STG + blk * BLK, 4 * wv + tl, 4 * cl, C_, REV_V, lp_vg) * 2u);
             }
         };
         auto load_gy = [&](int stg) {
 #pragma unroll
             for (int blk = 0; blk < SBLK; ++blk) {
-                const int p = stg * STG + blk * BLK + 4 * wv + tl;
-                cg[blk] = buf_load8(rs_g, (unsigned)(tokmap(p, REV_Y) * a.C + 4 * cl) * 2u);
+                cg[blk] = buf_load8(rs_g, tok.off(stg * STG + blk * BLK, 4 * wv + tl, 4 * cl, C_, REV_Y, lp_vg) * 2u);
             }
         };
         auto copy_v = [&](int stg) {       // cv -> K part of stage stg; kept in cvp for the stage's vg
@@ -1093,7 +1092,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             }
             float old_gv[SBLK][4] = {};                            // (second half of wkv6_bi: the first half's gv, a pre-phase ahead)
 #pragma unroll
-            for (int blk = SBLK - 1; blk >= 0; --blk) fetch_old(2, rs_gv, grp * STG + blk * BLK + x, REV_V, 16 * wv + 4 * g, old_gv[blk]);
+            for (int blk = SBLK - 1; blk >= 0; --blk) fetch_old(2, rs_gv, grp * STG + blk * BLK, REV_V, old_gv[blk]);
             // ---- pre-phase: everything that does not depend on G
             if (SPLIT && wv < SBLK) {   // (no row waves in this workgroup) this wave's score tile of the stage: block wv
                 const char* const rb = rpart(grp, wv);
@@ -1247,10 +1246,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     }
 }
 
-template <bool W_RAW, int GEN, bool SPLIT>
+template <bool W_RAW, int GEN, bool SPLIT, bool AFF>
 __global__ __launch_bounds__(SPLIT ? 512 : 768) void chunk_bwd12k_kernel(const ScanArgs a)
 {
-    chunk_bwd12k_body<W_RAW, GEN, SPLIT, GEN == 0>(a, blockIdx.x);
+    chunk_bwd12k_body<W_RAW, GEN, SPLIT, AFF, GEN == 0>(a, blockIdx.x);
 }
 
 // the backward of chunk_fwd_pair_kernel (wkv6_chunk.hip): two problems of one shape, slots [0, B H) serve a0, the rest a1
@@ -1259,7 +1258,7 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_pair_kernel(const ScanArgs a
 {
     const unsigned n = (unsigned)(a0.B * a0.H);
     const bool second = blockIdx.x >= n;
-    chunk_bwd12k_body<W_RAW, 0, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);
+    chunk_bwd12k_body<W_RAW, 0, false, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);   // (per-tensor reversal maps: general addressing)
 }
 
 // Both halves of wkv6_bi in one persistent launch (cuda/wkv6_bi_cuda.cu:363-377 runs one forward and three backward launches): workgroup
@@ -1279,29 +1278,37 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_bi_kernel(const ScanArgs a1,
     for (unsigned it = 0; it * gridDim.x < n; ++it) {
         const unsigned row = it * gridDim.x + ((it & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x);
         if (row >= n) continue;                                     // (the last round may be short; workgroup-uniform)
-        chunk_bwd12k_body<W_RAW, 1, false>(a1, row, blockIdx.x);
+        chunk_bwd12k_body<W_RAW, 1, false, true>(a1, row, blockIdx.x);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's partial stores are out ...
         __syncthreads();                                            // ... and every wave's (the LDS tags are re-armed behind this barrier)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         ScanArgs a2 = a1;
         a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.gu = nullptr; a2.ckpt = ckpt2;
-        chunk_bwd12k_body<W_RAW, 2, false>(a2, row, blockIdx.x);
+        chunk_bwd12k_body<W_RAW, 2, false, true>(a2, row, blockIdx.x);
         __syncthreads();
     }
 }
 
-template <bool W_RAW, int GEN> hipError_t launch_bwd12k_inst(const ScanArgs& a, hipStream_t st)
+template <bool W_RAW, int GEN, bool AFF> hipError_t launch_bwd12k_inst2(const ScanArgs& a, hipStream_t st)
 {
     constexpr size_t lds = BWD12K_LDS;
     static LdsAttrOnce attr, attr_split;       // per instantiation and device
     if (a.split) {
-        if (hipError_t e = attr_split.ensure(reinterpret_cast<const void*>(chunk_bwd12k_kernel<W_RAW, GEN, true>), lds)) return e;
-        hipLaunchKernelGGL((chunk_bwd12k_kernel<W_RAW, GEN, true>), dim3(2 * a.B * a.H), dim3(512), lds, st, a);
+        if (hipError_t e = attr_split.ensure(reinterpret_cast<const void*>(chunk_bwd12k_kernel<W_RAW, GEN, true, AFF>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_kernel<W_RAW, GEN, true, AFF>), dim3(2 * a.B * a.H), dim3(512), lds, st, a);
     } else {
-        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12k_kernel<W_RAW, GEN, false>), lds)) return e;
-        hipLaunchKernelGGL((chunk_bwd12k_kernel<W_RAW, GEN, false>), dim3(a.B * a.H), dim3(768), lds, st, a);
+        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(chunk_bwd12k_kernel<W_RAW, GEN, false, AFF>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_kernel<W_RAW, GEN, false, AFF>), dim3(a.B * a.H), dim3(768), lds, st, a);
     }
     return hipGetLastError();
+}
+// per-tensor reversal maps (a.rev_n: the compositions' *_rev_ex calls) take the general token addressing; the halves of wkv6_bi never
+// carry one
+template <bool W_RAW, int GEN> hipError_t launch_bwd12k_inst(const ScanArgs& a, hipStream_t st)
+{
+    if constexpr (GEN == 0) { if (a.rev_n) return launch_bwd12k_inst2<W_RAW, 0, false>(a, st); }
+    else if (a.rev_n) return hipErrorNotSupported;
+    return launch_bwd12k_inst2<W_RAW, GEN, true>(a, st);
 }
 template <bool W_RAW> hipError_t launch_bwd12k_variant(const ScanArgs& a, hipStream_t st)
 {

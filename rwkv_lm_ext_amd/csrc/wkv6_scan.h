@@ -112,6 +112,32 @@ __device__ __forceinline__ RevMap make_revmap(const ScanArgs& a, int b, int ntok
     return RevMap{0, 0u};
 }
 
+// Token addressing of the chunked kernels' global accesses.  AFF (chosen by the launchers: no per-tensor reversal map, a.rev_n == nullptr):
+// scan position p of the row is token t0 + sgn * p of EVERY tensor (0, +1; or ntok - 1, -1 under a.reverse), so the element offset of
+// (position pu + plane, channel ch) splits into a loop-invariant lane part, computed once in front of the stage loops, and a wave-uniform
+// part that the scalar unit forms: one vector add per access where the general map costs a compare, a select, a subtraction and an
+// integer multiply (quarter rate) per access (round 5: ~45 of the backward's 1066 vector instructions per SIMD and stage).  Positions past the
+// end map past the end (or below zero = far above it as unsigned): outside the row's buffer resources, as with the general map.
+template <bool AFF>
+struct TokAddr {
+    RevMap m;
+    int t0, sgn;
+    __device__ __forceinline__ TokAddr(const ScanArgs& a, int b, int ntok) : m(make_revmap(a, b, ntok))
+    {
+        t0 = m.mask ? ntok - 1 : 0;
+        sgn = m.mask ? -1 : 1;
+    }
+    // lane part of the element offset: position `plane` within the uniform base, channel ch, `stride` elements between tokens
+    __device__ __forceinline__ int lane(int plane, int ch, int stride) const { return AFF ? (t0 + sgn * plane) * stride + ch : 0; }
+    __device__ __forceinline__ int token(int p, unsigned bit) const { return AFF ? t0 + sgn * p : m(p, bit); }
+    // element offset of (position pu + plane, channel ch): pu wave-uniform; lane_part = lane(plane, ch, stride)
+    __device__ __forceinline__ unsigned off(int pu, int plane, int ch, int stride, unsigned bit, int lane_part) const
+    {
+        if constexpr (AFF) return (unsigned)(lane_part + pu * (sgn * stride));
+        else return (unsigned)(m(pu + plane, bit) * stride + ch);
+    }
+};
+
 enum { IO_BF16 = 0, IO_F32 = 1, IO_F16 = 2 };   // I/O element type of the scan forward (fp16: inference entry point only)
 hipError_t launch_scan_fwd(const ScanArgs& a, int io, hipStream_t st);
 hipError_t launch_scan_bwd(const ScanArgs& a, bool io_f32, hipStream_t st);

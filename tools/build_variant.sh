@@ -1,12 +1,29 @@
 #!/bin/bash
-# Cross-compile a variant library in this container: bash tools/build_variant.sh <name> "<extra flags>"  ->  build_ab/<name>/lib.so
-# (build_ab/ is git-ignored but travels to the GPU box with the snapshot; use with RWKV_AMD_LIB=build_ab/<name>/lib.so)
+# A/B variant of the library from the working tree: bash tools/build_variant.sh <name> ["-DFLAG ..."] [file.hip ...]
+# Compiles the named sources (default: the two chunked kernels) with the extra flags, takes every other object from the cache
+# build_ab/_obj (filled on first use from the working tree, refreshed with `bash tools/build_variant.sh --refresh`), links
+# build_ab/<name>/lib.so.  Use with tools/abn.sh / RWKV_AMD_LIB.
 set -e
-name=$1; flags=$2
-d=build_ab/$name; mkdir -p $d
-for f in wkv6_scan wkv6_chunk wkv6_chunk_bwd12k wkv6_mix wkv6_api; do
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-strict-aliasing $flags -c rwkv_lm_ext_amd/csrc/$f.hip -o $d/$f.o &
+cd "$(dirname "$0")/.."
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-strict-aliasing -w"
+SRCS="wkv6_scan wkv6_chunk wkv6_chunk_bwd12k wkv6_mix wkv6_api"
+mkdir -p build_ab/_obj
+refresh() { for s in $SRCS; do hipcc $FLAGS -c rwkv_lm_ext_amd/csrc/$s.hip -o build_ab/_obj/$s.o & done; wait; }
+if [ "$1" = "--refresh" ]; then refresh; exit 0; fi
+name=$1; extra=$2; shift; shift || true
+files=${@:-"wkv6_chunk wkv6_chunk_bwd12k"}
+for s in $SRCS; do [ -f build_ab/_obj/$s.o ] || { refresh; break; }; done
+mkdir -p build_ab/$name
+objs=""
+for s in $SRCS; do
+    if echo " $files " | grep -q " $s "; then
+        hipcc $FLAGS $extra -c rwkv_lm_ext_amd/csrc/$s.hip -o build_ab/$name/$s.o &
+        objs="$objs build_ab/$name/$s.o"
+    else
+        objs="$objs build_ab/_obj/$s.o"
+    fi
 done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o $d/lib.so $d/*.o
-echo built $d/lib.so
+hipcc --offload-arch=gfx950 -shared -fPIC -o build_ab/$name/lib.so $objs
+rm -f build_ab/$name/*.o
+ls -la build_ab/$name/lib.so

@@ -17,7 +17,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "rwkv_lm_ext_amd", "csrc", "wkv6_chunk_bwd12k.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-w", "-S", "--cuda-device-only"]
-KERNELS = ("chunk_bwd12k_kernelILb1ELi0ELb0EEE", "chunk_bwd12k_kernelILb0ELi0ELb0EEE")    # raw-w / fp32-ew, plain stores, one workgroup per pair
+KERNELS = ("chunk_bwd12k_kernelILb1ELi0ELb0ELb1EEE", "chunk_bwd12k_kernelILb0ELi0ELb0ELb1EEE")    # raw-w / fp32-ew, plain stores, one workgroup per pair
 
 
 def stage_loops(asm, kernel_substr):
@@ -88,7 +88,7 @@ def check(verbose=False):
         subprocess.check_call(["hipcc"] + FLAGS + ["-o", out, SRC], stderr=subprocess.DEVNULL)
         asm = open(out).read()
     bad = []
-    for kern in KERNELS + ("chunk_bwd12k_kernelILb1ELi1ELb0EEE", "chunk_bwd12k_kernelILb1ELi2ELb0EEE", "chunk_bwd12k_pair_kernelILb1EEE"):
+    for kern in KERNELS + ("chunk_bwd12k_kernelILb1ELi1ELb0ELb1EEE", "chunk_bwd12k_kernelILb1ELi2ELb0ELb1EEE", "chunk_bwd12k_pair_kernelILb1EEE"):
         rel = release_order(asm, kern)
         if verbose:
             print(f"{kern}: operand releases (tag offset, transposed reads in the 80 lines before): {rel}")

@@ -157,8 +157,8 @@ def main():
             out = os.path.join(tmp, src + ".s")
             subprocess.check_call(["hipcc"] + im.FLAGS + ["-o", out, os.path.join(args.csrc, src)], stderr=subprocess.DEVNULL)
             res[src] = open(out).read()
-    for label, src, sub, kind, tokens, waves, full in (("forward", "wkv6_chunk.hip", "chunk_fwd_kernelILb1ELb0ELb0ELb0EEE", "fwd", 64, 2, 2.2),
-                                                       ("backward", "wkv6_chunk_bwd12k.hip", "chunk_bwd12k_kernelILb1ELi0ELb0EEE", "bwd", 32, 3, 2.7)):
+    for label, src, sub, kind, tokens, waves, full in (("forward", "wkv6_chunk.hip", "chunk_fwd_kernelILb1ELb0ELb0ELb0ELb1EEE", "fwd", 64, 2, 2.2),
+                                                       ("backward", "wkv6_chunk_bwd12k.hip", "chunk_bwd12k_kernelILb1ELi0ELb0ELb1EEE", "bwd", 32, 3, 2.7)):
         nm, rows = walk(res[src], sub, kind, full, args.ops)
         print(f"\n== {label}: {nm[:90]}\n   per loop iteration = {tokens} tokens of one (batch, head); one SIMD hosts one wave of every role ({waves} waves per SIMD); "
               f"full-rate VALU priced at {full} cycles")

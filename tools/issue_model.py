@@ -152,8 +152,8 @@ def main():
             out = os.path.join(tmp, src + ".s")
             subprocess.check_call(["hipcc"] + FLAGS + ["-o", out, os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
             res[src] = open(out).read()
-    fwd = table(res["wkv6_chunk.hip"], "chunk_fwd_kernelILb1ELb0ELb0ELb0EEE", "fwd", 64)
-    bwd = table(res["wkv6_chunk_bwd12k.hip"], "chunk_bwd12k_kernelILb1ELi0ELb0EEE", "bwd", 32)
+    fwd = table(res["wkv6_chunk.hip"], "chunk_fwd_kernelILb1ELb0ELb0ELb0ELb1EEE", "fwd", 64)
+    bwd = table(res["wkv6_chunk_bwd12k.hip"], "chunk_bwd12k_kernelILb1ELi0ELb0ELb1EEE", "bwd", 32)
     # a SIMD hosts one wave of every role: what it must issue per loop iteration
     for label, rows, tokens, waves in (("forward", fwd, 64, 2), ("backward", bwd, 32, 3)):
         by = {}
