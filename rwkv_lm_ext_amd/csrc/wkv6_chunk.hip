@@ -31,6 +31,7 @@
 //
 // Decays smaller than e^LW_MIN per token are clamped (their true effect on any output is < 1.3e-4 of the
 // carried state, far below bf16 output resolution); the exact scan kernels remain available (WKV6_ALGO_SCAN).
+#include <type_traits>
 #include "wkv6_chunk.h"
 
 namespace wkv6 {
@@ -171,7 +172,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float l = valid ? fmaxf(lw[c], LW_MIN2) : 0.f;      // log2 units from here on
-                    cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + l;          // inclusive, within this lane's 4 tokens
+                    cs[tt][c] = tt ? cs[tt - 1][c] + l : l;              // inclusive, within this lane's 4 tokens
                 }
                 if constexpr (!STATE_ONLY) {
                     // bonus coefficient of the diagonal: sum over the 64 channels = 4 in-lane x 16 lanes of the row
@@ -189,7 +190,12 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             // what the CU's vector-memory pipe moves in a group at ~10 B per cycle, profiles/r05_fwd_prep_stamps.txt; v moved by the
             // consumer waves instead -- which wait ~1800 cycles at the group barrier -- as two 16-byte-per-lane loads a group ahead: +3 %,
             // profiles/r05_fwd_v_by_consumers.txt)
-            if (next >= 0) load_group(next);
+#ifndef WKV6_NO_LOADFENCE
+            // (the raw registers are dead here -- kept so: left to itself hipcc sinks the decay arithmetic below the requests, whose
+            // destinations are the raw registers, and copies all eight of them out of the way first)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            load_group(next);
             WKV6_TP(1);
             float pre[4], c8[4], c16[4];
 #pragma unroll
@@ -267,22 +273,23 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             WKV6_TP(4);
         };
 
+        // (the next group's requests go out unconditionally: past the last group they lie past the end of the buffer resources and cost
+        // nothing -- as a conditional they made the raw registers a merge of "loaded" and "kept", which hipcc resolved with sixteen register
+        // copies and a full s_waitcnt vmcnt(0) per group; the last group's barrier is peeled off the loop for the same reason)
         if (ngrp > 0) {
             load_group(0);
-            prep_group(0, 0, ngrp > 1 ? 1 : -1);
+            prep_group(0, 0, 1);
         }
         __syncthreads();
-        for (int grp = 0; grp < ngrp; ++grp) {
+        for (int grp = 0; grp + 1 < ngrp; ++grp) {
             WKV6_T(ts0);
 #ifdef WKV6_STAMP
             asm volatile("" :: "v"(pr[0].x), "v"(pk[0].x), "v"(pv[0].x), "v"(pw[0].x), "v"(pr[3].x), "v"(pk[3].x), "v"(pv[3].x),
                          "v"(pw[3].x));                                  // wait for the loads here
 #endif
             WKV6_T(ts1);
-            if (grp + 1 < ngrp) {
-                prep_group(grp + 1, (grp + 1) & 1, grp + 2 < ngrp ? grp + 2 : -1);
-                WKV6_T(ts2);
-            }
+            prep_group(grp + 1, (grp + 1) & 1, grp + 2);
+            WKV6_T(ts2);
             WKV6_T(ts3);
             __syncthreads();
             WKV6_T(ts4);
@@ -292,6 +299,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             WKV6_ACC(5, ts4, ts3);                            // (barrier wait)
 #endif
         }
+        if (ngrp > 0) __syncthreads();                        // the last group is consumed
         if (a.dsum && tq == 0 && part == 0)
             *reinterpret_cast<float4*>(a.dsum + ((long)(b * a.H + h) * 4 + wv) * HEAD + 4 * c4) = make_float4(dtot[0], dtot[1], dtot[2], dtot[3]);
     } else {
@@ -376,12 +384,15 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         auto stage_y = [&](int grp_, int blk, uint2 yb) {
             *reinterpret_cast<uint2*>(ys + (grp_ & 1) * YS_BYTES + (BLK * blk + x) * YRS + 32 * hwid + 8 * g) = yb;
         };
+        const int fl_chunk = lane & ((1 << ylsh) - 1);
+        const int fl_row[2] = {(GRP >> (ylsh - 1)) * hwid + (lane >> ylsh), (GRP >> (ylsh - 1)) * hwid + (64 >> ylsh) + (lane >> ylsh)};
+        const int lp_fl[2] = {tok.lane(fl_row[0], 32 * part + 8 * fl_chunk, C_), tok.lane(fl_row[1], 32 * part + 8 * fl_chunk, C_)};
         auto flush_y = [&](int grp_) {     // after the barrier that closed group grp_: every consumer's pieces of it are in the image
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int row = (GRP >> (ylsh - 1)) * hwid + (64 >> ylsh) * i + (lane >> ylsh), chunk = lane & ((1 << ylsh) - 1);
+                const int row = fl_row[i], chunk = fl_chunk;
                 const uint4 v = *reinterpret_cast<const uint4*>(ys + (grp_ & 1) * YS_BYTES + row * YRS + 16 * chunk);
-                const unsigned off = tok.off(grp_ * GRP, row, 32 * part + 8 * chunk, C_, REV_Y, tok.lane(row, 32 * part + 8 * chunk, C_)) * 2u;
+                const unsigned off = tok.off(grp_ * GRP, row, 32 * part + 8 * chunk, C_, REV_Y, lp_fl[i]) * 2u;
                 buf_store16(rs_y, off, v);                         // (tokens past the end: dropped by the bounds check)
             }
         };
