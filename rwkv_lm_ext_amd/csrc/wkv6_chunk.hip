@@ -226,7 +226,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 float rh[4], kh[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float cex = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
+                    const float cex = tt ? pre[c] + cs[tt - 1][c] : pre[c];
                     const float cin = pre[c] + cs[tt][c];
                     rh[c] = r[tt][c] * exp2_fast(cex - c8[c]);
                     kh[c] = k[tt][c] * exp2_fast(c8[c] - cin);

@@ -377,7 +377,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float l = valid ? fmaxf(lw[c] * LOG2E, LW_MIN2) : 0.f;   // the decay the block algebra uses, in log2 units
-                    cs[tt][c] = (tt ? cs[tt - 1][c] : 0.f) + l;
+                    cs[tt][c] = tt ? cs[tt - 1][c] + l : l;
                     // gw multiplier: the true lw, times d_true / d_clamped where the clamp is active (the algebra yields the
                     // exact gradient of the clamped model, d_clamped * X; the true one is d_true * X)
                     lwn[tt][c] = valid ? lw[c] : 0.f;
@@ -437,7 +437,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             float kh[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float cex = pre[c] + (tt ? cs[tt - 1][c] : 0.f);
+                const float cex = tt ? pre[c] + cs[tt - 1][c] : pre[c];
                 const float cin = pre[c] + cs[tt][c];
                 cfr[tt][c] = cex - c8[c];                                // fR = 2^this, formed with the stage's R part
                 clw[tt][c] = lwn[tt][c];
