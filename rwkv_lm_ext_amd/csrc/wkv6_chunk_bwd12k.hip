@@ -258,10 +258,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // hands to its R part one iteration later (raw k, exponents of fR, the gw multipliers, c_8)
     uint2 pr[2], pk[2], pw[2];
     float4 pe[2];
-    uint2 nr[2], nk[2], nw[2];
-    float4 ne[2];
     uint2 ck_[2];
-    uint2 nv[2], ng[2], pv[2], pg[2], cv_[2];                         // SPLIT: the producers also move v (K part) and gy (R part)
+    uint2 pv[2], pg[2], cv_[2];                         // SPLIT: the producers also move v (K part) and gy (R part)
     float cfr[2][4], clw[2][4], cc8[4] = {0.f, 0.f, 0.f, 0.f};
     const rsrc_t rs_r = make_rsrc(gr_, nbytes), rs_k = make_rsrc(gk_, nbytes), rs_v = make_rsrc(gv_, nbytes), rs_g = make_rsrc(ggy, nbytes);
     const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, nbytes)
@@ -270,8 +268,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     auto load_r = [&](int stg) {       // tokens past the end load zeros
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            nr[tt] = buf_load8(rs_r, tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_R, lp_in[tt]) * 2u);
-            if constexpr (SPLIT) ng[tt] = buf_load8(rs_g, tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_Y, lp_in[tt]) * 2u);
+            pr[tt] = buf_load8(rs_r, tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_R, lp_in[tt]) * 2u);
+            if constexpr (SPLIT) pg[tt] = buf_load8(rs_g, tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_Y, lp_in[tt]) * 2u);
         }
     };
     auto load_kw = [&](int stg) {
@@ -279,36 +277,17 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         for (int tt = 0; tt < 2; ++tt) {
             const int pl = pb * BLK + 2 * tq + tt;
             const unsigned ik = tok.off(stg * STG, pl, ch0, C_, REV_K, lp_in[tt]), iw = tok.off(stg * STG, pl, ch0, C_, REV_W, lp_in[tt]);
-            nk[tt] = buf_load8(rs_k, ik * 2u);
-            if constexpr (SPLIT) nv[tt] = buf_load8(rs_v, tok.off(stg * STG, pl, ch0, C_, REV_V, lp_in[tt]) * 2u);
-            if constexpr (W_RAW) nw[tt] = buf_load8(rs_w, iw * 2u);
-            else ne[tt] = buf_load16f(rs_w, iw * 4u);
+            pk[tt] = buf_load8(rs_k, ik * 2u);
+            if constexpr (SPLIT) pv[tt] = buf_load8(rs_v, tok.off(stg * STG, pl, ch0, C_, REV_V, lp_in[tt]) * 2u);
+            if constexpr (W_RAW) pw[tt] = buf_load8(rs_w, iw * 2u);
+            else pe[tt] = buf_load16f(rs_w, iw * 4u);
         }
     };
-    // the loaded set becomes the working set (register moves: the next loads may then overwrite n*)
-    auto take_r = [&]() {
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            pr[tt] = nr[tt];
-            if constexpr (SPLIT) pg[tt] = ng[tt];
-        }
-        asm volatile("" : "+v"(pr[0].x), "+v"(pr[0].y), "+v"(pr[1].x), "+v"(pr[1].y));
-        if constexpr (SPLIT) asm volatile("" : "+v"(pg[0].x), "+v"(pg[0].y), "+v"(pg[1].x), "+v"(pg[1].y));
-    };
-    auto take_kw = [&]() {
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            pk[tt] = nk[tt];
-            if constexpr (SPLIT) pv[tt] = nv[tt];
-            if constexpr (W_RAW) pw[tt] = nw[tt]; else pe[tt] = ne[tt];
-        }
-        if constexpr (SPLIT) asm volatile("" : "+v"(pv[0].x), "+v"(pv[0].y), "+v"(pv[1].x), "+v"(pv[1].y));
-        if constexpr (W_RAW)
-            asm volatile("" : "+v"(pk[0].x), "+v"(pk[0].y), "+v"(pk[1].x), "+v"(pk[1].y), "+v"(pw[0].x), "+v"(pw[0].y), "+v"(pw[1].x), "+v"(pw[1].y));
-        else
-            asm volatile("" : "+v"(pk[0].x), "+v"(pk[0].y), "+v"(pk[1].x), "+v"(pk[1].y),
-                              "+v"(pe[0].x), "+v"(pe[0].y), "+v"(pe[0].z), "+v"(pe[0].w), "+v"(pe[1].x), "+v"(pe[1].y), "+v"(pe[1].z), "+v"(pe[1].w));
-    };
+    // (round 5: no second register set.  The requests for the stages behind go out from INSIDE the preparation, right behind the last read of
+    // the raw registers they refill -- a few hundred cycles later than in front of it, of the 5000+ they have -- which saves the twelve
+    // register copies per stage that handed a loaded set over to the working set, and they are unconditional: past the first stage they lie
+    // below the buffer resources' range and cost nothing, where a conditional request makes its destination a merge the compiler resolves
+    // with more copies)
     // One iteration of the producers: the R part of stage sr (Rhat hi | lo, fR, lw, raw r / k, E8, r.u.k -- from r and from what the
     // K part of that stage left in ck_, cfr, clw, cc8 an iteration ago) and the K part of stage sk = sr - 1 (decays, prefix sums,
     // Khat hi | lo, E16, E16m8; refills ck_, cfr, clw, cc8).  Either may be absent (sr / sk < 0: pipeline head and tail).  The two
@@ -318,7 +297,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // (profiles/r04_stamps_bwd12k_v1.txt).
     // (HASR / HASK are compile-time: a run-time `if (sk >= 0)` would cut the body into the very basic blocks it is meant to avoid;
     // the lane-predicated stores -- r.u.k, E8, E16, E16m8 -- come last for the same reason)
-    auto prep = [&](auto HASR, auto HASK, int sr, int sk) {
+    auto prep = [&](auto HASR, auto HASK, int sr, int sk, int next_r, int next_k) {   // next_*: stages whose r / k, w are requested (any stage < 0: none)
         char* const rb = rpart(HASR ? sr : 0, pb);
         char* const kb = kpart(HASK ? sk : 0, pb);
         float r[2][4], ko[2][4], k[2][4], cs[2][4], lwn[2][4], coef[2] = {0.f, 0.f};
@@ -356,6 +335,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 }
             }
         }
+        if constexpr (HASR) load_r(next_r);                      // (pr, pg are dead)
         // ---- K, first half: log-decays of the stage's tokens, their sums inside the lane, the gw multipliers
         if constexpr (HASK) {
 #pragma unroll
@@ -390,6 +370,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #pragma unroll
                     for (int c = 0; c < 4; ++c) lwn[tt][c] *= exp2_fast(LOG2E * fminf(lwn[tt][c] - LW_MIN, 0.f));
             }
+            load_kw(next_k);                                      // (pk, pw / pe, pv are dead)
         } else {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
@@ -493,7 +474,18 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // behind them is preceded by an `asm volatile` that consumes their result: volatile asm statements and volatile accesses are not
     // reordered among each other.  A tag is the stage index + 1 and every role executes every stage: a reader can only ever wait for
     // a tag that some wave is about to write.
-    auto publish = [&](int idx, int tag) { if (lane == 0) *xflag_at(idx) = tag; };   // after this wave's (volatile) tile store
+    // (tag stores, round 5: the LDS address of a tag is wave-uniform, and so is its value -- left to the compiler every store moved both
+    // from scalar registers into fresh vector registers first, 2 of the ~10 vector issue slots a role spends on its 4-5 publications per
+    // stage.  The slot address of tag group 0 for this wave (tag_wv: + 4 wv; tag_tb: + 8 (wv & 1), the dA tiles' pairs) is kept in a vector
+    // register for the kernel's life, a tag group's distance is an immediate, the value is moved once per stage.)
+    unsigned tag_wv = (unsigned)(unsigned long)(lds_vint*)(smem + XFLAG_OFF + 4 * wv);
+    unsigned tag_tb = (unsigned)(unsigned long)(lds_vint*)(smem + XFLAG_OFF + 8 * (wv & 1));
+    asm volatile("" : "+v"(tag_wv), "+v"(tag_tb));
+    auto tag_off = [](int idx0) { return (idx0 >> 3) * RSB + (idx0 & 7) * 4; };       // idx0: a tag group's first slot (a multiple of 4)
+    auto publish_at = [&](unsigned base, int idx0, int extra, int tagv) {             // after this wave's (volatile) tile store
+        if (lane == 0) *(lds_vint*)(unsigned long)(base + (unsigned)(tag_off(idx0) + extra)) = tagv;
+    };
+    auto publish = [&](int idx0, int tagv) { publish_at(tag_wv, idx0, 0, tagv); };       // slot idx0 + wv
 #ifdef WKV6_DEBUG
     // debug build: a poll that does not see its tag within ~2^22 tries writes (slot, tag index, expected, seen) to the debug buffer and traps
     auto spin_fail = [&](int idx, int tag, unsigned seen) {
@@ -548,17 +540,9 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         if (ngrp > 0) {
             load_kw(ngrp - 1);
             load_r(ngrp - 1);
-            take_kw();
-            take_r();
-            if (ngrp > 1) load_kw(ngrp - 2);
-            prep(no_c, yes_c, -1, ngrp - 1);                       // K part of the last stage
-            if (ngrp > 1) {
-                take_kw();
-                load_r(ngrp - 2);
-                if (ngrp > 2) load_kw(ngrp - 3);
-            }
-            if (ngrp > 1) prep(yes_c, yes_c, ngrp - 1, ngrp - 2);  // its R part, and the K part of the stage in front
-            else prep(yes_c, no_c, 0, -1);
+            prep(no_c, yes_c, -1, ngrp - 1, -1, ngrp - 2);          // K part of the last stage (requests k, w of the stage in front)
+            if (ngrp > 1) prep(yes_c, yes_c, ngrp - 1, ngrp - 2, ngrp - 2, ngrp - 3);  // its R part, and the K part of the stage in front
+            else prep(yes_c, no_c, 0, -1, -1, -1);
         }
         __syncthreads();
         // steady state: stages ngrp-1 .. 2 (a full R + K preparation each); the last two stages are peeled so that the loop body
@@ -566,25 +550,18 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         for (int grp = ngrp - 1; grp >= 2; --grp) {
             WKV6_T(ts0);
 #ifdef WKV6_STAMP
-            asm volatile("" :: "v"(nr[0].x), "v"(nk[0].x), "v"(nr[1].x), "v"(nk[1].x));      // wait for the loads here
+            asm volatile("" :: "v"(pr[0].x), "v"(pk[0].x), "v"(pr[1].x), "v"(pk[1].x));      // wait for the loads here
 #endif
             WKV6_T(ts1);
-            // the consuming roles are light enough that a stage waits for the producers: the next requests go out BEFORE the
-            // preparation and fly during all of it
-            take_r();                                              // r of stage s-1
-            take_kw();                                             // k, w of stage s-2
-            load_r(grp - 2);
-            if (grp > 2) load_kw(grp - 3);
             WKV6_T(ts2);
-            prep(yes_c, yes_c, grp - 1, grp - 2);
+            prep(yes_c, yes_c, grp - 1, grp - 2, grp - 2, grp - 3);   // r of stage s-1, k / w of stage s-2; requests r of s-2, k / w of s-3
             WKV6_T(ts3);
             __syncthreads();
             WKV6_T(ts4);
             WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3);
         }
         if (ngrp >= 2) {                                           // stage 1 is consumed: only the R part of stage 0 is left to make
-            take_r();
-            prep(yes_c, no_c, 0, -1);
+            prep(yes_c, no_c, 0, -1, -1, -1);
             __syncthreads();
         }
         if (ngrp >= 1) __syncthreads();                            // stage 0 is consumed
@@ -652,6 +629,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 
         __syncthreads();                                          // first stage image is ready
         for (int grp = ngrp - 1; grp >= 0; --grp) {
+            int tagv = grp + 1;                                    // this stage's tag value, in a vector register (see publish)
+            asm volatile("" : "+v"(tagv));
             WKV6_T(ts0);
             // ---- G-dependent part of gk, decoupled from the epilogues: sum_j (E16m8 G)[i][j] v_b[j] per block from the operand
             //      the column waves publish; block 1's version is taken (and released: GB) here, block 0's behind the pre-phase
@@ -680,7 +659,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 gvb[1] = take_gop(1);
                 // released at once: the reads are in this wave's LDS queue, which is served in order, and the tag store cannot be moved
                 // above loads it may alias (their address is opaque to the compiler) -- no need to wait for their data here
-                publish(TAG_GB + wv, grp + 1);
+                publish(TAG_GB, tagv);
                 WKV6_EV(1);
             }
             // (second half of wkv6_bi: the first half's gr of both blocks, requested a pre-phase ahead of the sums they meet)
@@ -711,10 +690,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 uint2 th, tl;
                 split4(dab, th, tl, spc);
                 tile_store(XT_OFF + (2 * tb) * 1024, th, tl);
-                publish(TAG_DA + 2 * tb, grp + 1);
+                publish_at(tag_tb, TAG_DA, 0, tagv);            // slot TAG_DA + 2 tb
                 split4(dba, th, tl, spc);
                 tile_store(XT_OFF + (2 * tb + 1) * 1024, th, tl);
-                publish(TAG_DA + 2 * tb + 1, grp + 1);
+                publish_at(tag_tb, TAG_DA, 4, tagv);            // slot TAG_DA + 2 tb + 1
             } else if constexpr (!SPLIT) {   // row waves 0 and 1: the masked score tile of block wv, for the column waves
                 const char* const rb = rpart(grp, wv);
                 const char* const kb = kpart(grp, wv);
@@ -740,7 +719,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 uint2 th, tl;
                 split4(scm, th, tl, spc);
                 tile_store(XS_OFF + wv * 1024, th, tl);
-                publish(TAG_SC + wv, grp + 1);
+                publish(TAG_SC, tagv);
             }
             // stage-entry forward state: the checkpoint of this 64-token pair (requested a stage's chain ago); the odd stage of a pair
             // first walks it through the two blocks of the even stage in front (their K part is already in the ring)
@@ -848,7 +827,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 gvb[0] = take_gop(0);
                 // Released for the column waves (they lay the NEXT stage's first operand over it): this wave's reads are in the LDS
                 // queue, which serves a wave's requests in order, and a store is never moved above a load it may alias.
-                publish(TAG_GD + wv, grp + 1);
+                publish(TAG_GD, tagv);
             }
 #pragma unroll
             for (int blk = SBLK - 1; blk >= 0; --blk) put(0, rs_gr, grp, blk, REV_R, held_gr[blk]);
@@ -1037,6 +1016,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         __syncthreads();                                          // first stage image is ready
         if constexpr (!SPLIT) { if (ngrp > 0) scale_split(kpart(ngrp - 1, SBLK - 1), nh, nl); }
         for (int grp = ngrp - 1; grp >= 0; --grp) {
+            int tagv = grp + 1;                                    // this stage's tag value, in a vector register (see publish)
+            asm volatile("" : "+v"(tagv));
             WKV6_T(ts0);
 
             // ---- the stage's G recurrence: per block (1, then 0) the operand (E16m8 (.) G) hi | lo for the row waves (stored [j][i]: this
@@ -1059,7 +1040,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     for (int s = 0; s < 2; ++s) { gh[blk][s] = nh[s]; gl[blk][s] = nl[s]; }   // made (and published) in the previous stage's tail
                     if (grp == ngrp - 1) {
                         gop_write(gh[blk], gl[blk]);
-                        publish(TAG_GA + wv, grp + 1);
+                        publish(TAG_GA, tagv);
                     }
                     WKV6_EV(0);
                     WKV6_T5(2, tp0);
@@ -1072,7 +1053,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     await4(TAG_GB, grp + 1);     // the row waves have taken block 1's version
                     WKV6_EV(2);
                     gop_write(gh[blk], gl[blk]);
-                    publish(TAG_GC + wv, grp + 1);
+                    publish(TAG_GC, tagv);
                     WKV6_EV(3);
                 }
                 const s4v gyT = tr_read(rb + R_GY * ARR + troff + 32 * wv);           // gy[4g+e][16wv + x]
@@ -1119,7 +1100,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 uint2 th, tl;
                 split4(scm, th, tl, spc);
                 tile_store(XS_OFF + wv * 1024, th, tl);
-                publish(TAG_SC + wv, grp + 1);
+                publish(TAG_SC, tagv);
             }
 #pragma unroll
             for (int blk = 0; blk < SBLK; ++blk) gyT_w[blk] = tr_read(rpart(grp, blk) + R_GY * ARR + troff + 32 * wv);   // gy[4g+e][16wv + x]
@@ -1197,7 +1178,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     scale_split(kpart(grp - 1, SBLK - 1), nh, nl);
                     await4(TAG_GD, grp + 1);                       // every row wave has taken block 0's operand of this stage
                     gop_write(nh, nl);
-                    publish(TAG_GA + wv, grp);                     // (ordered before the row waves' reads by the stage barrier as well)
+                    publish(TAG_GA, tagv - 1);                     // (ordered before the row waves' reads by the stage barrier as well)
                 }
             }
             if (!SPLIT && grp > 0) copy_gy(grp - 1);           // (uses cvp = v of stage s-1, before copy_v replaces it)

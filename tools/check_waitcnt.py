@@ -59,10 +59,10 @@ def stage_loops(asm, kernel_substr):
     return [(k, v["stores"], v["loads"], v["waits"]) for k, v in loops.items()]
 
 
-# The row waves release the published G operand (tags GB / GD, LDS byte offsets 304 / 464 of the tag rows) right behind their reads of
+# The row waves release the published G operand (tags GB / GD, immediate offsets 176 / 336 from the wave's tag base register: wkv6_chunk_bwd12k.hip, publish) right behind their reads of
 # it, without waiting for the data: correct because the LDS serves a wave's requests in order AND the compiler keeps the tag store
 # behind the eight transposed reads (it may alias them).  This lists, for every tag store, how many of those reads precede it closely.
-RELEASE_TAG_OFFSETS = (304, 464)
+RELEASE_TAG_OFFSETS = (176, 336)
 
 
 def release_order(asm, kernel_substr, window=80):
