@@ -62,8 +62,50 @@ constexpr int YS_BYTES = GRP * YRS;
 // The kernel proper is a device function of (arguments, workgroup slot): chunk_fwd_kernel runs it on its one argument block,
 // chunk_fwd_pair_kernel (the two WKV problems of a bidirectional composition in ONE launch) on one of two.
 // CLK: the in-run clock probe (wkv6_set_clock_buffer) is compiled into the plain kernel only.
-template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN, bool AFF, bool CLK = false>
-__device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot, const unsigned sslot = 0)
+// The producers' raw input registers of a call.  In the persistent wkv6_bi launch (CHAIN) they outlive the call: a call's producers, idle
+// while the consumers work through its last group, prepare group 0 of the NEXT call (the row's reversed half, or the slot's next row) and
+// leave that call's group 1 in flight into these registers.
+struct FwdRaw {
+    uint2 pr[4], pk[4], pv[4], pw[4];
+    float4 pe[4];
+};
+// group `grp` of problem (a, slot), block wv, requested into raw -- the one definition of "which bytes": the body's own requests and the
+// previous call's early one must agree
+template <bool W_RAW, bool STATE_ONLY, bool AFF>
+__device__ __forceinline__ void fwd_request_group(const ScanArgs& a, const int b, const int h, const int ntok, const int rev, const int grp, const int wv,
+                                                  const int lane, FwdRaw& raw)   // rev: the row reversed (a's own reversal fields are not read)
+{
+    const int c4 = lane & 15, tq = lane >> 4;
+    const long base = (long)b * a.T * a.C + (long)h * HEAD;
+    const TokAddr<AFF> tok(ntok, rev != 0);
+    const int C_ = a.C;
+    const unsigned span = ntok > 0 ? (unsigned)(ntok - 1) * a.C : 0u;
+    const unsigned nb2 = ntok > 0 ? span * 2 + 128 : 0;
+    const rsrc_t rs_r = make_rsrc(reinterpret_cast<const bf16_t*>(a.r) + base, nb2), rs_k = make_rsrc(reinterpret_cast<const bf16_t*>(a.k) + base, nb2);
+    const rsrc_t rs_v = make_rsrc(reinterpret_cast<const bf16_t*>(a.v) + base, nb2);
+    const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, nb2)
+                              : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? span * 4 + 256 : 0);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int pl = wv * BLK + 4 * tq + tt, lp = tok.lane(pl, 4 * c4, C_);
+        if constexpr (!STATE_ONLY) raw.pr[tt] = buf_load8(rs_r, tok.off(grp * GRP, pl, 4 * c4, C_, REV_R, lp) * 2);
+        else raw.pr[tt] = make_uint2(0u, 0u);
+        raw.pk[tt] = buf_load8(rs_k, tok.off(grp * GRP, pl, 4 * c4, C_, REV_K, lp) * 2);
+        raw.pv[tt] = buf_load8(rs_v, tok.off(grp * GRP, pl, 4 * c4, C_, REV_V, lp) * 2);
+        if constexpr (W_RAW) raw.pw[tt] = buf_load8(rs_w, tok.off(grp * GRP, pl, 4 * c4, C_, REV_W, lp) * 2);
+        else raw.pe[tt] = buf_load16f(rs_w, tok.off(grp * GRP, pl, 4 * c4, C_, REV_W, lp) * 4);
+    }
+}
+// CHAIN: raw is the launch's carried register set; (nxvalid, nxbh, nxrev) the call that follows this one in the workgroup slot: row nxbh of this
+// problem -- the same argument block: a pointer to another one would put both into scratch memory --, reversed or not (nxvalid), with the
+// bonus term or not (nx_use_u).  Its producers, idle while the consumers work through the call's last group, PREPARE group 0 of that next call
+// (the pipeline fill, one group's time per call, 12 calls per slot at BASELINE configs[2]) into the operand buffer the last group does not use:
+// group g of a call lives in buffer (g + pb) & 1, and a call that was prepared for (chained_in) has neither prologue nor opening barrier.
+template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN, bool AFF, bool CLK = false, bool CHAIN = false>
+__device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot, const unsigned sslot, FwdRaw& raw,
+                                               const bool nxvalid = false, const unsigned nxbh = 0, const int nxrev = 0,
+                                               const int b_known = -1, const int ntok_known = 0, const int nxb = 0, const int nxntok = 0,
+                                               const int pb = 0, const bool chained_in = false, const bool nx_use_u = false)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2] | float [4 consumers][1024] | y rows [2][64][YRS]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -76,7 +118,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
     const int wid = a.split ? (hwid < 2 ? 2 * part + hwid : hwid + 2) : hwid;
     const bool producer = wid >= 4;
     const int wv = wid & 3;                                          // block (producer) / column tile (consumer)
-    const int b = a.order ? a.order[bh / a.H] : bh / a.H, h = bh % a.H;
+    // (CHAIN: the persistent launch has looked the row's batch index and length up -- two dependent memory round trips -- a call ahead)
+    const int b = CHAIN ? b_known : (a.order ? a.order[bh / a.H] : bh / a.H), h = bh % a.H;
     const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
                                                               // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
     const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
@@ -84,7 +127,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
     const bf16_t* const gv_ = reinterpret_cast<const bf16_t*>(a.v) + base;
     bf16_t* const gy_ = reinterpret_cast<bf16_t*>(a.y) + base;
     int ntok = a.T;
-    if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
+    if constexpr (CHAIN) ntok = ntok_known;
+    else if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const int ngrp = (ntok + GRP - 1) / GRP;
     const TokAddr<AFF> tok(a, b, ntok);                           // token addressing (wkv6_scan.h): AFF = no per-tensor reversal map
     const int C_ = a.C;
@@ -102,8 +146,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         const int c4 = lane & 15, tq = lane >> 4;                    // 4 channels x 4 tokens per lane
         float uu[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + h * HEAD + 4 * c4, uu);
-        uint2 pr[4], pk[4], pv[4], pw[4];
-        float4 pe[4];
+        uint2 (&pr)[4] = raw.pr, (&pk)[4] = raw.pk, (&pv)[4] = raw.pv, (&pw)[4] = raw.pw;
+        float4 (&pe)[4] = raw.pe;
         float dtot[4] = {0.f, 0.f, 0.f, 0.f};                            // log2-decay summed over this wave's blocks (a.dsum)
         // buffer resources over this row's first ntok tokens: loads of tokens past the end return 0 without a branch
         const unsigned span = ntok > 0 ? (unsigned)(ntok - 1) * a.C : 0u;     // elements up to the last token's head slice
@@ -143,7 +187,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 #else
 #define WKV6_TP(n) do { } while (0)
 #endif
-        auto prep_group = [&](int grp, int buf, int next) {
+        auto prep_group = [&](int grp, int buf, const int ntok, const float (&uu)[4], auto&& request_next) {
             char* const bb = smem + buf * GRP_BYTES + wv * BLK_BYTES;
             float r[4][4], k[4][4], cs[4][4];
 #if defined(WKV6_STAMP) && defined(WKV6_STAMP_PREP)
@@ -195,7 +239,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             // destinations are the raw registers, and copies all eight of them out of the way first)
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            load_group(next);
+            request_next();
             WKV6_TP(1);
             float pre[4], c8[4], c16[4];
 #pragma unroll
@@ -276,11 +320,16 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         // (the next group's requests go out unconditionally: past the last group they lie past the end of the buffer resources and cost
         // nothing -- as a conditional they made the raw registers a merge of "loaded" and "kept", which hipcc resolved with sixteen register
         // copies and a full s_waitcnt vmcnt(0) per group; the last group's barrier is peeled off the loop for the same reason)
-        if (ngrp > 0) {
-            load_group(0);
-            prep_group(0, 0, 1);
+        // (CHAIN: the bonus vector of the call that follows, requested here, used at this call's end)
+        float uu_nx[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (CHAIN) { if (nxvalid && nx_use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + (nxbh % (unsigned)a.H) * HEAD + 4 * c4, uu_nx); }
+        if (!(CHAIN && chained_in)) {
+            if (ngrp > 0) {
+                load_group(0);
+                prep_group(0, pb & 1, ntok, uu, [&]() { load_group(1); });
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (int grp = 0; grp + 1 < ngrp; ++grp) {
             WKV6_T(ts0);
 #ifdef WKV6_STAMP
@@ -288,7 +337,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                          "v"(pw[3].x));                                  // wait for the loads here
 #endif
             WKV6_T(ts1);
-            prep_group(grp + 1, (grp + 1) & 1, grp + 2);
+            prep_group(grp + 1, (grp + 1 + pb) & 1, ntok, uu, [&]() { load_group(grp + 2); });
             WKV6_T(ts2);
             WKV6_T(ts3);
             __syncthreads();
@@ -298,6 +347,14 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 #else
             WKV6_ACC(5, ts4, ts3);                            // (barrier wait)
 #endif
+        }
+        if constexpr (CHAIN) {
+            // the consumers are busy with this call's last group: the raw registers are dead, the next call's first inputs can fly
+            if (nxvalid) {
+                const int nxh = (int)(nxbh % (unsigned)a.H);
+                fwd_request_group<W_RAW, STATE_ONLY, AFF>(a, nxb, nxh, nxntok, nxrev, 0, wv, lane, raw);
+                prep_group(0, (ngrp + pb) & 1, nxntok, uu_nx, [&]() { fwd_request_group<W_RAW, STATE_ONLY, AFF>(a, nxb, nxh, nxntok, nxrev, 1, wv, lane, raw); });
+            }
         }
         if (ngrp > 0) __syncthreads();                        // the last group is consumed
         if (a.dsum && tq == 0 && part == 0)
@@ -429,7 +486,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 }
             }
         };
-        __syncthreads();
+        if (!(CHAIN && chained_in)) __syncthreads();            // (a call that was prepared for: the barriers that closed the call before it)
         constexpr bool STAGE_Y = !STATE_ONLY && !GN;              // (bf16 y of this launch goes through the staged rows; a y_f32 first half stores directly)
         const bool staged = STAGE_Y && (ACC || !a.y_f32);
         for (int grp = 0; grp < ngrp; ++grp) {
@@ -455,7 +512,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             constexpr int unroll_by = unrolled ? NBLK : 1;
 #pragma unroll unroll_by
             for (int blk = 0; blk < nb; ++blk) {
-                const char* const bb = smem + (grp & 1) * GRP_BYTES + blk * BLK_BYTES;
+                const char* const bb = smem + ((grp + pb) & 1) * GRP_BYTES + blk * BLK_BYTES;
                 typedef unsigned v4u __attribute__((ext_vector_type(4)));
                 v4u ckd[4];
                 int ck_off = -1;                                  // >= 0: a row-order checkpoint waits in ckd for its stores
@@ -599,6 +656,16 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 else io4<bf16_t>::store(reinterpret_cast<bf16_t*>(a.s_out) + so_ + tile_ch(it), t4);
             }
         }
+        if constexpr (CHAIN) {
+            // a consumer wave carries nothing from call to call: "define" the carried registers here (no instruction), or the compiler keeps
+            // them alive -- 32 to 48 registers -- through all of the consumer path for the producer waves' sake
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                asm volatile("" : "=v"(raw.pr[tt].x), "=v"(raw.pr[tt].y), "=v"(raw.pk[tt].x), "=v"(raw.pk[tt].y),
+                                  "=v"(raw.pv[tt].x), "=v"(raw.pv[tt].y), "=v"(raw.pw[tt].x), "=v"(raw.pw[tt].y));
+                asm volatile("" : "=v"(raw.pe[tt].x), "=v"(raw.pe[tt].y), "=v"(raw.pe[tt].z), "=v"(raw.pe[tt].w));
+            }
+        }
     }
 #ifdef WKV6_DEBUGBUF
     WKV6_CLK(clk1, rtc1);
@@ -622,7 +689,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN, bool AFF>
 __global__ __launch_bounds__(512) void chunk_fwd_kernel(const ScanArgs a)
 {
-    chunk_fwd_body<W_RAW, STATE_ONLY, ACC, GN, AFF, !STATE_ONLY && !ACC && !GN>(a, blockIdx.x);
+    FwdRaw raw;
+    chunk_fwd_body<W_RAW, STATE_ONLY, ACC, GN, AFF, !STATE_ONLY && !ACC && !GN>(a, blockIdx.x, 0u, raw);
 }
 
 // Two problems of the same shape in one grid of 2 B H workgroups: slots [0, B H) serve a0, the rest a1 (src/model_bi.py:331-348,
@@ -632,7 +700,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_pair_kernel(const ScanArgs a0, 
 {
     const unsigned n = (unsigned)(a0.B * a0.H);
     const bool second = blockIdx.x >= n;                      // workgroup-uniform: the argument block is read through one of two
-    chunk_fwd_body<W_RAW, false, false, false, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);   // kernarg addresses; per-tensor reversal maps: general addressing
+    FwdRaw raw;
+    chunk_fwd_body<W_RAW, false, false, false, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x, 0u, raw);   // kernarg addresses; per-tensor reversal maps: general addressing
 }
 
 // Both halves of wkv6_bi in one persistent launch (cuda/wkv6_bi_cuda.cu:363-368 is one launch too): workgroup slot s walks the rows
@@ -646,17 +715,46 @@ __global__ __launch_bounds__(512) void chunk_fwd_bi_kernel(const ScanArgs a1, fl
     // the rows are ordered by decreasing length (a.order): slot j takes row j of the first round of gridDim.x rows, row gridDim.x - 1 - j
     // of the second, ... (boustrophedon), so that every slot gets long and short rows alike -- in plain round-robin order slot 0 would
     // take the longest row of every round and the last slot the shortest (+-12 % of the mean at BASELINE configs[2])
+    // (the producers' raw input registers outlive a call: each call's producers request the first inputs of the call that follows --
+    // FwdRaw above.  The producer waves write no global memory and take no part in the fences between the halves, which would make them
+    // wait for those requests.)
+    FwdRaw raw;
+    const bool producer_wave = (threadIdx.x >> 6) >= 4;
+    // a row's batch index and length: a.order[row / H] -> a.lens[b], two dependent memory round trips that used to open every call; looked up
+    // one row ahead here
+    const auto row_of = [&](unsigned it) { return it * gridDim.x + ((it & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x); };
+    const auto lookup = [&](unsigned row, int& b, int& ntok) {
+        b = 0; ntok = 0;
+        if (row < n) {
+            b = a1.order ? a1.order[row / a1.H] : (int)(row / a1.H);
+            ntok = a1.lens ? min(max(a1.lens[b], 0), a1.T) : a1.T;
+        }
+    };
+    int b_cur, ntok_cur;
+    lookup(row_of(0), b_cur, ntok_cur);
+    int pb = 0;                                                     // operand buffer of a call's group 0 (see chunk_fwd_body, CHAIN)
+    bool chained = false;                                           // the call that starts has been prepared for by the one before it
     for (unsigned it = 0; it * gridDim.x < n; ++it) {
-        const unsigned row = it * gridDim.x + ((it & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x);
+        const unsigned row = row_of(it);
         if (row >= n) continue;                                     // (the last round may be short; workgroup-uniform)
-        chunk_fwd_body<W_RAW, false, false, false, true>(a1, row, blockIdx.x);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const unsigned row_nx = row_of(it + 1);
+        int b_nx, ntok_nx;
+        lookup(row_nx, b_nx, ntok_nx);
+        const int ngrp_cur = (ntok_cur + GRP - 1) / GRP;
+        chunk_fwd_body<W_RAW, false, false, false, true, false, true>(a1, row, blockIdx.x, raw, true, row, 1, b_cur, ntok_cur, b_cur, ntok_cur,
+                                                                      pb, chained, false);
+        pb = (pb + ngrp_cur) & 1;
+        if (!producer_wave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (!producer_wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         ScanArgs a2 = a1;
         a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.ckpt = ckpt2;
-        chunk_fwd_body<W_RAW, false, true, false, true>(a2, row, blockIdx.x);
+        chunk_fwd_body<W_RAW, false, true, false, true, false, true>(a2, row, blockIdx.x, raw, row_nx < n, row_nx, 0, b_cur, ntok_cur, b_nx, ntok_nx,
+                                                                     pb, true, a1.use_u != 0);
+        pb = (pb + ngrp_cur) & 1;
+        chained = true;
         __syncthreads();
+        b_cur = b_nx; ntok_cur = ntok_nx;
     }
 }
 

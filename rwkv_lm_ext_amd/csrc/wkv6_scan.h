@@ -127,6 +127,13 @@ struct TokAddr {
         t0 = m.mask ? ntok - 1 : 0;
         sgn = m.mask ? -1 : 1;
     }
+    // (explicit form: the whole row reversed or not -- the persistent wkv6_bi launches address the call that FOLLOWS the one whose argument
+    // block they hold)
+    __device__ __forceinline__ TokAddr(int ntok, bool rev) : m(RevMap{rev ? ntok : 0, rev ? (unsigned)REV_ALL : 0u})
+    {
+        t0 = rev ? ntok - 1 : 0;
+        sgn = rev ? -1 : 1;
+    }
     // lane part of the element offset: position `plane` within the uniform base, channel ch, `stride` elements between tokens
     __device__ __forceinline__ int lane(int plane, int ch, int stride) const { return AFF ? (t0 + sgn * plane) * stride + ch : 0; }
     __device__ __forceinline__ int token(int p, unsigned bit) const { return AFF ? t0 + sgn * p : m(p, bit); }
