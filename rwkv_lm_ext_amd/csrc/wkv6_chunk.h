@@ -131,13 +131,8 @@ __device__ __forceinline__ void split4(const float (&x)[4], uint2& hi, uint2& lo
     const bf2 m10 = __builtin_bit_cast(bf2, sc.c10), m01 = __builtin_bit_cast(bf2, sc.c01);
     hi.x = pack_bf2(x[0], x[1]);
     hi.y = pack_bf2(x[2], x[3]);
-#ifdef WKV6_SPLIT_NODOT
-    // A/B variant (profiles/r05_issue_floor.md): lo = x - float(hi) by unpack (shift / and) + subtract on the plain vector ALU.
-    // v_dot2c_f32_bf16 issues at half rate like the shift, but it shares a pipe with the MFMAs of the SIMD's other waves.
-    lo.x = pack_bf2(x[0] - bf_lo(hi.x), x[1] - bf_hi(hi.x));
-    lo.y = pack_bf2(x[2] - bf_lo(hi.y), x[3] - bf_hi(hi.y));
-    return;
-#endif
+    // (lo = x - float(hi) by unpack + subtract on the plain vector ALU instead: 1.5 instructions per element, forward +3-5 %, backward
+    // +2-4 %: profiles/r05_pk_dot2c_ab.txt)
     const bf2 h0 = __builtin_bit_cast(bf2, hi.x), h1 = __builtin_bit_cast(bf2, hi.y);
     lo.x = pack_bf2(__builtin_amdgcn_fdot2_f32_bf16(h0, m10, x[0], false), __builtin_amdgcn_fdot2_f32_bf16(h0, m01, x[1], false));
     lo.y = pack_bf2(__builtin_amdgcn_fdot2_f32_bf16(h1, m10, x[2], false), __builtin_amdgcn_fdot2_f32_bf16(h1, m01, x[3], false));

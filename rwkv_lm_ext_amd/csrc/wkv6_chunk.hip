@@ -234,11 +234,9 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             // what the CU's vector-memory pipe moves in a group at ~10 B per cycle, profiles/r05_fwd_prep_stamps.txt; v moved by the
             // consumer waves instead -- which wait ~1800 cycles at the group barrier -- as two 16-byte-per-lane loads a group ahead: +3 %,
             // profiles/r05_fwd_v_by_consumers.txt)
-#ifndef WKV6_NO_LOADFENCE
             // (the raw registers are dead here -- kept so: left to itself hipcc sinks the decay arithmetic below the requests, whose
             // destinations are the raw registers, and copies all eight of them out of the way first)
             __builtin_amdgcn_sched_barrier(0);
-#endif
             request_next();
             WKV6_TP(1);
             float pre[4], c8[4], c16[4];

@@ -203,22 +203,15 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     typedef volatile v4u_t __attribute__((address_space(3))) lds_vv4u;
-#ifndef WKV6_STORE_MODE
-#define WKV6_STORE_MODE 1        // experiment switch: 0 = 8-byte stores per block
-#endif
     [[maybe_unused]] uint2 held_st[4] = {};
     auto put = [&](int which, const rsrc_t& rs, int stg, int blk, unsigned bit, uint2 v) {   // this lane: token x_ of the block, channels 16 wv + 4 g_ .. + 3
         if constexpr (GEN == 1) return;                            // (went to the fp32 side buffer in emit)
-#if WKV6_STORE_MODE == 0
-        buf_store8(rs, tok.off(stg * STG + blk * BLK, x_, 16 * wv + 4 * g_, C_, bit, tok.lane(x_, 16 * wv + 4 * g_, C_)) * 2u, v);
-#else
         if (blk == SBLK - 1) { held_st[which] = v; return; }      // (the stage's blocks are walked 1, 0)
         const auto sx = __builtin_amdgcn_permlane16_swap(held_st[which].x, v.x, false, false);
         const auto sy = __builtin_amdgcn_permlane16_swap(held_st[which].y, v.y, false, false);
         // even lane rows: block 1's token, odd rows: block 0's
         buf_store16(rs, tok.off(stg * STG, ((g_ & 1) ? 0 : BLK) + x_, 16 * wv + 8 * (g_ >> 1), C_, bit, lp_put) * 2u,
                     make_uint4(sx[0], sy[0], sx[1], sy[1]));
-#endif
     };
     // the result of one block: fp32 side buffer (first half of wkv6_bi: 64-byte pieces, 16 bytes per lane as they are) or the packed
     // bf16 quad for `put`
@@ -624,7 +617,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         {   // (first half of wkv6_bi: four fp32 side stores -- gk, gw of both blocks -- follow a stage's checkpoint request)
             const rsrc_t rs_none = make_rsrc(static_cast<bf16_t*>(nullptr), 0u);
 #pragma unroll
-            for (int i = 0; i < (GEN == 1 ? 4 : WKV6_STORE_MODE == 0 ? 6 : 3); ++i) buf_store16(rs_none, 16u * i, make_uint4(0u, 0u, 0u, 0u));   // (distinct: identical ones are merged)
+            for (int i = 0; i < (GEN == 1 ? 4 : 3); ++i) buf_store16(rs_none, 16u * i, make_uint4(0u, 0u, 0u, 0u));   // (distinct: identical ones are merged)
         }
 
         __syncthreads();                                          // first stage image is ready
