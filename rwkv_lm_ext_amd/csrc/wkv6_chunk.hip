@@ -257,8 +257,6 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             if (tq == 0) {
                 *reinterpret_cast<float4*>(bb + OFF_E8 + 16 * c4) =
                     make_float4(exp2_fast(c8[0]), exp2_fast(c8[1]), exp2_fast(c8[2]), exp2_fast(c8[3]));
-                *reinterpret_cast<float4*>(bb + OFF_E16 + 16 * c4) =
-                    make_float4(exp2_fast(c16[0]), exp2_fast(c16[1]), exp2_fast(c16[2]), exp2_fast(c16[3]));
                 *reinterpret_cast<float4*>(bb + OFF_E16M8 + 16 * c4) =
                     make_float4(exp2_fast(c16[0] - c8[0]), exp2_fast(c16[1] - c8[1]), exp2_fast(c16[2] - c8[2]), exp2_fast(c16[3] - c8[3]));
             }
@@ -545,27 +543,40 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                 [[maybe_unused]] uint4 scp = {};
                 [[maybe_unused]] float4 pm0[2] = {}, pm1[2] = {};
                 [[maybe_unused]] b8v pzh[2] = {}, pzl[2] = {};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    pm0[s] = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g) * 4);
+                    pm1[s] = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g + 4) * 4);
+                }
                 if constexpr (!STATE_ONLY) {
                     scp = *reinterpret_cast<const uint4*>(bb + OFF_SC + lane * 16);
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        pm0[s] = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g) * 4);
-                        pm1[s] = *reinterpret_cast<const float4*>(bb + OFF_E8 + (32 * s + 8 * g + 4) * 4);
                         const int off = x * RSB + (32 * s + 8 * g) * 2;
                         pzh[s] = ld_b8(bb + A_RH * ARR + off);
                         pzl[s] = ld_b8(bb + A_RL * ARR + off);
                     }
                 }
                 b8v pk8[4];                                         // Khat (hi | lo along K) of tile `it`
-                float4 pd16[4], pdm[4];
+                float4 pdm[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     pk8[it] = __builtin_bit_cast(b8v, __builtin_shufflevector(tr_read(bb + A_KH * ARR + trow + tile_tr(it)),
                                                                               tr_read(bb + A_KL * ARR + trow + tile_tr(it)), 0, 1, 2, 3, 4, 5, 6, 7));
-                    pd16[it] = *reinterpret_cast<const float4*>(bb + OFF_E16 + (tile_ch(it) + 8 * g) * 4);
                     pdm[it] = *reinterpret_cast<const float4*>(bb + OFF_E16M8 + (tile_ch(it) + 8 * g) * 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // T = E8 (.) S, tile by tile (tiles 2s, 2s + 1 = k-slots e = 0..3, 4..7 of k-step s): the operand of (3) -- and, since
+                // E16 = E16m8 E8, the state one block on is E16m8 (.) (T + Khat^T V): T goes into the MFMA of (4) as its accumulator and
+                // the update is ONE multiplication per element (round 5; it was E16 (.) S + E16m8 (.) (Khat^T V): a multiplication and an fma,
+                // and a second decay vector to read)
+                f4v Tt[4];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float4 m0 = pm0[s], m1 = pm1[s];
+                    Tt[2 * s] = f4v{St[2 * s][0] * m0.x, St[2 * s][1] * m0.y, St[2 * s][2] * m0.z, St[2 * s][3] * m0.w};
+                    Tt[2 * s + 1] = f4v{St[2 * s + 1][0] * m1.x, St[2 * s + 1][1] * m1.y, St[2 * s + 1][2] * m1.z, St[2 * s + 1][3] * m1.w};
+                }
                 if constexpr (!STATE_ONLY) {
                     // (1) masked transposed scores, prepared by the producer of this block: hi | lo along K
                     // (2) y^T[j][a] = sum_b V[b][j] sc[b][a]: (V | V) x (sc_hi ; sc_lo), one MFMA.  Every MFMA of this wave is a
@@ -576,10 +587,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                     // (3) y^T[j][a] += sum_i (E8 S)[i][j] Rhat[a][i]; k-slot (s, g, e) <-> channel 32s + 8g + e
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const float4 m0 = pm0[s], m1 = pm1[s];
-                        const float t0[4] = {St[2 * s][0] * m0.x, St[2 * s][1] * m0.y, St[2 * s][2] * m0.z, St[2 * s][3] * m0.w};
-                        const float t1[4] = {St[2 * s + 1][0] * m1.x, St[2 * s + 1][1] * m1.y,
-                                             St[2 * s + 1][2] * m1.z, St[2 * s + 1][3] * m1.w};
+                        const float t0[4] = {Tt[2 * s][0], Tt[2 * s][1], Tt[2 * s][2], Tt[2 * s][3]};
+                        const float t1[4] = {Tt[2 * s + 1][0], Tt[2 * s + 1][1], Tt[2 * s + 1][2], Tt[2 * s + 1][3]};
                         uint2 h0, l0, h1, l1;
                         split4(t0, h0, l0, spc);
                         split4(t1, h1, l1, spc);
@@ -617,16 +626,15 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
                         }
                     }
                 }
-                // (4) S[it] <- E16 (.) S[it] + E16m8 (.) (Khat^T V)
+                // (4) S[it] <- E16m8 (.) (T[it] + Khat^T V)   (= E16 (.) S[it] + E16m8 (.) (Khat^T V))
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    f4v o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma32(pk8[it], vf, o);                      // (Khat_hi | Khat_lo)^T (V ; V)
-                    const float4 d16 = pd16[it], dm = pdm[it];
-                    St[it][0] = fmaf(d16.x, St[it][0], dm.x * o[0]);
-                    St[it][1] = fmaf(d16.y, St[it][1], dm.y * o[1]);
-                    St[it][2] = fmaf(d16.z, St[it][2], dm.z * o[2]);
-                    St[it][3] = fmaf(d16.w, St[it][3], dm.w * o[3]);
+                    const f4v o = mfma32(pk8[it], vf, Tt[it]);       // T + (Khat_hi | Khat_lo)^T (V ; V)
+                    const float4 dm = pdm[it];
+                    St[it][0] = dm.x * o[0];
+                    St[it][1] = dm.y * o[1];
+                    St[it][2] = dm.z * o[2];
+                    St[it][3] = dm.w * o[3];
                 }
                 if (ck_off >= 0) {
 #pragma unroll
