@@ -76,3 +76,35 @@ def test_no_scratch_access_inside_any_loop_and_no_spill_in_the_benched_kernels()
                     in_loop, persistent = False, "_bi_kernel" in line
                 elif in_loop and line.strip().startswith("scratch_"):
                     raise AssertionError(f"{src}: scratch access inside a loop: {line.strip()}")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_no_integer_multiply_in_the_benched_kernels_loops():
+    """Round 5: token offsets are a hoisted lane part + a wave-uniform part formed on the scalar unit (wkv6_scan.h:
+    TokAddr).  The general reversal map cost a compare, a select, a subtraction and a quarter-rate 32-bit multiply per access; the benched
+    instantiations (no per-tensor reversal map) must have none of those multiplies left inside a group / stage loop."""
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-w", "-S", "--cuda-device-only"]
+    wanted = {"wkv6_chunk.hip": ("chunk_fwd_kernelILb1ELb0ELb0ELb0ELb1E", "chunk_fwd_kernelILb0ELb0ELb0ELb0ELb1E"),
+              "wkv6_chunk_bwd12k.hip": ("chunk_bwd12k_kernelILb1ELi0ELb0ELb1E", "chunk_bwd12k_kernelILb0ELi0ELb0ELb1E")}
+    with tempfile.TemporaryDirectory() as tmp:
+        for src, names in wanted.items():
+            out = os.path.join(tmp, src + ".s")
+            subprocess.check_call(["hipcc"] + flags + ["-o", out, os.path.join(root, "rwkv_lm_ext_amd", "csrc", src)])
+            seen = 0
+            for fn in re.split(r"\n(?=_Z[\w]+:)", open(out).read()):
+                name = fn.split(":", 1)[0]
+                if not any(n in name for n in names):
+                    continue
+                seen += 1
+                in_loop = False
+                for line in fn.split("\n"):
+                    m = re.match(r"^\.LBB\d+_\d+:\s*(;.*)?$", line)
+                    if m:
+                        in_loop = "Loop" in (m.group(1) or "")
+                    elif in_loop and re.match(r"\s+v_(mul_lo_u32|mul_hi_u32|mad_u64_u32)", line):
+                        raise AssertionError(f"{name}: integer multiply inside a loop: {line.strip()}")
+            assert seen == len(names), (src, seen)
