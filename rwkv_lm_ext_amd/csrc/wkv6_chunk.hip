@@ -47,7 +47,8 @@ constexpr int CKX_BYTES = 4 * 4096;         // checkpoint transposition buffers 
 // 0.190-0.202 (tools/microbench/head_slices.hip: fwd_shapes, profiles/r05_head_slices_microbench.txt).  So the consumers park a
 // group's y (bf16) in a double-buffered [64 tokens][144 B] image and, behind the group barrier they have anyway, each stores 16
 // whole rows of the group with two 16-byte-per-lane instructions.
-constexpr int CONSUMER_STAGGER = 4;         // s_sleep units (64 cycles) by which consumer w trails consumer w - 1 into a group
+constexpr int CONSUMER_STAGGER = 3;         // s_sleep units (64 cycles) by which consumer w trails consumer w - 1 into a group (4 until the
+                                            // producers' serial path got shorter late in round 5; re-tuned: profiles/r05_stagger.txt)
 constexpr int YRS = 144;                    // staged y row: 128 B + 16 B pad (16-byte row reads stay aligned; writes are 2-way at most)
 constexpr int YS_BYTES = GRP * YRS;
 
@@ -488,9 +489,10 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         for (int grp = 0; grp < ngrp; ++grp) {
             WKV6_T(ts0);
             // The four consumers leave the group barrier together, burst their block operands' LDS reads at the same moments -- and then wait
-            // ~1300 cycles for the producers at the next barrier.  Consumer w starts a group w x 256 cycles late: the bursts no longer
+            // ~1300 cycles for the producers at the next barrier.  Consumer w starts a group w x 192 cycles late (256 when this was measured): the bursts no longer
             // collide (nor with the producers' stores), the delay comes out of the barrier wait.  Same box: forward -2.7 % (0.2198 ->
-            // 0.2137 ms; 128 or 448 cycles per wave -0.8 / -1.5 %; staggering the producers too +1.2 ... 2 %: profiles/r05_stagger.txt).
+            // 0.2137 ms; 128 or 448 cycles per wave -0.8 / -1.5 %; staggering the producers too +1.2 ... 2 %: profiles/r05_stagger.txt);
+            // 192 cycles per wave since the end of round 5 (another -3.4 % after the producers' path had been shortened).
             for (int i_ = 0; i_ < hwid; ++i_) __builtin_amdgcn_s_sleep(CONSUMER_STAGGER);   // (hwid: the consumer's index within its workgroup)
             if (staged && grp > 0) flush_y(grp - 1);
             if constexpr (ACC) acc_request(grp + 1, acc_nxt);     // (past the last group: past the end of the resource, reads zero)
