@@ -1010,6 +1010,9 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         if constexpr (!SPLIT) { if (ngrp > 0) scale_split(kpart(ngrp - 1, SBLK - 1), nh, nl); }
         for (int grp = ngrp - 1; grp >= 0; --grp) {
             int tagv = grp + 1;                                    // this stage's tag value, in a vector register (see publish)
+            // (column wave w enters a stage w x 128 cycles late: the four waves' operand reads and G updates no longer burst at the same moment --
+            // same box -1 %, 64 / 192 cycles -0.4 %, 256 and more slower, the row waves staggered the same way +0.5 ... 1 %: profiles/r05_stagger.txt)
+            for (int i_ = 0; i_ < wv; ++i_) __builtin_amdgcn_s_sleep(2);
             asm volatile("" : "+v"(tagv));
             WKV6_T(ts0);
 
