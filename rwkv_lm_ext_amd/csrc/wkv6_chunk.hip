@@ -97,17 +97,26 @@ __device__ __forceinline__ void fwd_request_group(const ScanArgs& a, const int b
         else raw.pe[tt] = buf_load16f(rs_w, tok.off(grp * GRP, pl, 4 * c4, C_, REV_W, lp) * 4);
     }
 }
-// CHAIN: raw is the launch's carried register set; (nxvalid, nxbh, nxrev) the call that follows this one in the workgroup slot: row nxbh of this
-// problem -- the same argument block: a pointer to another one would put both into scratch memory --, reversed or not (nxvalid), with the
-// bonus term or not (nx_use_u).  Its producers, idle while the consumers work through the call's last group, PREPARE group 0 of that next call
-// (the pipeline fill, one group's time per call, 12 calls per slot at BASELINE configs[2]) into the operand buffer the last group does not use:
-// group g of a call lives in buffer (g + pb) & 1, and a call that was prepared for (chained_in) has neither prologue nor opening barrier.
+// What a call of the persistent wkv6_bi launch (CHAIN) knows beyond its argument block.  Its producers, idle while the consumers work through
+// the call's last group, PREPARE group 0 of the call that follows it in the workgroup slot (the pipeline fill: one group's time per call, 12
+// calls per slot at BASELINE configs[2]) into the operand buffer the last group does not use: group g of a call lives in buffer (g + pb) & 1,
+// and a call that was prepared for (chained_in) has neither prologue nor opening barrier.  The call that follows is row nx_bh of the SAME
+// argument block (a pointer to another block would put both into scratch memory), reversed or not, with the bonus term or not.
+struct FwdChain {
+    int b, ntok;                   // this call's batch index and row length (looked up a row ahead by the launch: order[] -> lens[])
+    int pb;                        // operand buffer of this call's group 0
+    bool chained_in;               // the call before this one has prepared this call's group 0 (and requested group 1)
+    bool nx_valid;                 // there is a call behind this one ...
+    unsigned nx_bh;                // ... on row nx_bh (batch index nx_b, length nx_ntok),
+    int nx_b, nx_ntok;
+    bool nx_rev, nx_use_u;         // reversed / with the bonus vector
+};
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN, bool AFF, bool CLK = false, bool CHAIN = false>
-__device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot, const unsigned sslot, FwdRaw& raw,
-                                               const bool nxvalid = false, const unsigned nxbh = 0, const int nxrev = 0,
-                                               const int b_known = -1, const int ntok_known = 0, const int nxb = 0, const int nxntok = 0,
-                                               const int pb = 0, const bool chained_in = false, const bool nx_use_u = false)
+__device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot, const unsigned sslot, FwdRaw& raw, const FwdChain& ch = FwdChain{})
 {
+    [[maybe_unused]] const bool nxvalid = ch.nx_valid, chained_in = ch.chained_in, nx_use_u = ch.nx_use_u;
+    [[maybe_unused]] const unsigned nxbh = ch.nx_bh;
+    [[maybe_unused]] const int nxrev = ch.nx_rev, b_known = ch.b, ntok_known = ch.ntok, nxb = ch.nx_b, nxntok = ch.nx_ntok, pb = CHAIN ? ch.pb : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][NBLK][BLK_BYTES] | GN: float [2][4 waves][NBLK][16][2] | float [4 consumers][1024] | y rows [2][64][YRS]
     const int tid = threadIdx.x, lane = tid & 63;
     const SplitConst spc = split_const();
@@ -749,16 +758,16 @@ __global__ __launch_bounds__(512) void chunk_fwd_bi_kernel(const ScanArgs a1, fl
         int b_nx, ntok_nx;
         lookup(row_nx, b_nx, ntok_nx);
         const int ngrp_cur = (ntok_cur + GRP - 1) / GRP;
-        chunk_fwd_body<W_RAW, false, false, false, true, false, true>(a1, row, blockIdx.x, raw, true, row, 1, b_cur, ntok_cur, b_cur, ntok_cur,
-                                                                      pb, chained, false);
+        chunk_fwd_body<W_RAW, false, false, false, true, false, true>(a1, row, blockIdx.x, raw,
+                                                                      FwdChain{b_cur, ntok_cur, pb, chained, true, row, b_cur, ntok_cur, true, false});
         pb = (pb + ngrp_cur) & 1;
         if (!producer_wave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         if (!producer_wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         ScanArgs a2 = a1;
         a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.ckpt = ckpt2;
-        chunk_fwd_body<W_RAW, false, true, false, true, false, true>(a2, row, blockIdx.x, raw, row_nx < n, row_nx, 0, b_cur, ntok_cur, b_nx, ntok_nx,
-                                                                     pb, true, a1.use_u != 0);
+        chunk_fwd_body<W_RAW, false, true, false, true, false, true>(a2, row, blockIdx.x, raw,
+                                                                     FwdChain{b_cur, ntok_cur, pb, true, row_nx < n, row_nx, b_nx, ntok_nx, false, a1.use_u != 0});
         pb = (pb + ngrp_cur) & 1;
         chained = true;
         __syncthreads();
