@@ -116,7 +116,7 @@ __device__ __forceinline__ RevMap make_revmap(const ScanArgs& a, int b, int ntok
 // scan position p of the row is token t0 + sgn * p of EVERY tensor (0, +1; or ntok - 1, -1 under a.reverse), so the element offset of
 // (position pu + plane, channel ch) splits into a loop-invariant lane part, computed once in front of the stage loops, and a wave-uniform
 // part that the scalar unit forms: one vector add per access where the general map costs a compare, a select, a subtraction and an
-// integer multiply (quarter rate) per access (round 5: ~45 of the backward's 1066 vector instructions per SIMD and stage).  Positions past the
+// integer multiply (half rate: 4.2 cycles, profiles/r05_issue2_microbench.txt) per access (round 5: ~45 of the backward's 1066 vector instructions per SIMD and stage).  Positions past the
 // end map past the end (or below zero = far above it as unsigned): outside the row's buffer resources, as with the general map.
 template <bool AFF>
 struct TokAddr {

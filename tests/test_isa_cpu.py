@@ -81,7 +81,7 @@ def test_no_scratch_access_inside_any_loop_and_no_spill_in_the_benched_kernels()
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
 def test_no_integer_multiply_in_the_benched_kernels_loops():
     """Round 5: token offsets are a hoisted lane part + a wave-uniform part formed on the scalar unit (wkv6_scan.h:
-    TokAddr).  The general reversal map cost a compare, a select, a subtraction and a quarter-rate 32-bit multiply per access; the benched
+    TokAddr).  The general reversal map cost a compare, a select, a subtraction and a (half-rate) 32-bit multiply per access; the benched
     instantiations (no per-tensor reversal map) must have none of those multiplies left inside a group / stage loop."""
     import re
     import subprocess

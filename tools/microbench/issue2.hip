@@ -89,6 +89,11 @@
 #define B_DSW64  "ds_write_b64 v121, v[64:65]\n ds_write_b64 v121, v[66:67] offset:512\n ds_write_b64 v121, v[68:69] offset:1024\n ds_write_b64 v121, v[70:71] offset:1536\n" \
                  "ds_write_b64 v121, v[72:73] offset:2048\n ds_write_b64 v121, v[74:75] offset:2560\n ds_write_b64 v121, v[76:77] offset:3072\n ds_write_b64 v121, v[78:79] offset:3584\n s_waitcnt lgkmcnt(4)\n"
 
+// integer multiplies (the general token map's offset arithmetic, gone from the benched kernels in round 5)
+#define B_MULLO  "v_mul_lo_u32 v80, v64, v65\n v_mul_lo_u32 v81, v65, v66\n v_mul_lo_u32 v82, v66, v67\n v_mul_lo_u32 v83, v67, v68\n" \
+                 "v_mul_lo_u32 v84, v68, v69\n v_mul_lo_u32 v85, v69, v70\n v_mul_lo_u32 v86, v70, v71\n v_mul_lo_u32 v87, v71, v72\n"
+#define B_MAD64  "v_mad_u64_u32 v[80:81], vcc, v64, v65, v[66:67]\n v_mad_u64_u32 v[82:83], vcc, v65, v66, v[68:69]\n v_mad_u64_u32 v[84:85], vcc, v66, v67, v[70:71]\n v_mad_u64_u32 v[86:87], vcc, v67, v68, v[72:73]\n" \
+                 "v_mad_u64_u32 v[88:89], vcc, v68, v69, v[74:75]\n v_mad_u64_u32 v[90:91], vcc, v69, v70, v[76:77]\n v_mad_u64_u32 v[92:93], vcc, v70, v71, v[64:65]\n v_mad_u64_u32 v[94:95], vcc, v71, v72, v[66:67]\n"
 // own-wave interleaving: one MFMA followed by six vector instructions (all independent)
 #define M1 "v_mfma_f32_16x16x32_bf16 v[104:107], v[96:99], v[100:103], v[104:107]\n"
 #define B_M_PKFMA M1 "v_pk_fma_f32 v[80:81], v[64:65], v[66:67], v[68:69]\n v_pk_fma_f32 v[82:83], v[66:67], v[68:69], v[70:71]\n v_pk_fma_f32 v[84:85], v[68:69], v[70:71], v[72:73]\n" \
@@ -114,7 +119,8 @@
     X(33, "split4 sequence (12 instr)", B_SPLIT4, 12) X(34, "mfma 16x16x32 bf16", B_MFMA32, 8) X(35, "mfma 16x16x16 bf16", B_MFMA16, 8) X(36, "mfma 16x16x32 dep", B_MFMA32_DEP, 8) \
     X(37, "ds_read_b128", B_DSR128, 8) X(38, "ds_read_b64_tr_b16", B_DSRTR, 8) X(39, "ds_write_b64", B_DSW64, 8) X(40, "v_fmac_f32", OP2("v_fmac_f32"), 8) \
     X(41, "own wave: mfma + 6 v_pk_fma_f32", B_M_PKFMA, 7) X(42, "own wave: mfma + 6 v_fma_f32", B_M_FMA6, 7) X(43, "own wave: mfma + 12 v_fma_f32", B_M_FMA12, 13) \
-    X(44, "own wave: mfma + 6 v_dot2c", B_M_DOT6, 7) X(45, "own wave: mfma + 6 v_cvt_pk", B_M_CVT6, 7)
+    X(44, "own wave: mfma + 6 v_dot2c", B_M_DOT6, 7) X(45, "own wave: mfma + 6 v_cvt_pk", B_M_CVT6, 7) \
+    X(46, "v_mul_lo_u32", B_MULLO, 8) X(47, "v_mad_u64_u32", B_MAD64, 8)
 constexpr int NKIND = 46;
 
 // role 0 = the class, role 1 = back-to-back MFMAs (16x16x32, four accumulators)
