@@ -121,8 +121,13 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 // tiles.  Every wave does the same arithmetic as in the one-workgroup launch: the outputs are bit-identical.
 // CLK: the in-run clock probe (wkv6_set_clock_buffer) is compiled into the plain kernel only (it costs ~6 SGPRs, which the wkv6_bi
 // and pair instantiations do not have).
-template <bool W_RAW, int GEN, bool SPLIT, bool AFF, bool CLK = false>
-__device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot, const unsigned sslot = 0)
+// What a call of the persistent wkv6_bi launch (CHAIN) knows beyond its argument block: the row's batch index and length, looked up a row ahead
+// by the launch (a.order[row / H] -> a.lens[b]: two dependent memory round trips, ~3000 cycles that used to open every call).
+struct BwdChain {
+    int b, ntok;
+};
+template <bool W_RAW, int GEN, bool SPLIT, bool AFF, bool CLK = false, bool CHAIN = false>
+__device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot, const unsigned sslot = 0, const BwdChain& ch = BwdChain{})
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][RBLK_BYTES] | [3][SBLK][KBLK_BYTES] | tiles | G operand
     const int tid = threadIdx.x, lane = tid & 63;
@@ -133,7 +138,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     const bool rowrole = wid < 4, producer = wid >= 8;
     const int wv = wid & 3;                                              // tile owned by a row / column wave
     const int pb = wid & 1, half = (wid >> 1) & 1;                       // producer: block of the stage, channel half
-    const int b = a.order ? a.order[bh / a.H] : bh / a.H, h = bh % a.H;
+    const int b = CHAIN ? ch.b : (a.order ? a.order[bh / a.H] : bh / a.H), h = bh % a.H;
     const long base = (long)b * a.T * a.C + (long)h * HEAD;   // (batch, head) origin: uniform, folded into the pointers;
                                                               // per-lane offsets below stay 32-bit (T*C < 2^31, checked by the API)
     const bf16_t* const gr_ = reinterpret_cast<const bf16_t*>(a.r) + base;
@@ -145,7 +150,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     bf16_t* const ogv = reinterpret_cast<bf16_t*>(a.gv) + base;
     bf16_t* const ogw = reinterpret_cast<bf16_t*>(a.gw) + base;
     int ntok = a.T;
-    if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
+    if constexpr (CHAIN) ntok = ch.ntok;
+    else if (a.lens) ntok = min(max(a.lens[b], 0), a.T);
     const TokAddr<AFF> tok(a, b, ntok);                       // token addressing (wkv6_scan.h): AFF = no per-tensor reversal map
     const int C_ = a.C;
     // buffer resources over this row's first ntok tokens (wkv6_common.h): loads past the end return 0, stores are dropped
@@ -1252,17 +1258,30 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_bi_kernel(const ScanArgs a1,
     // the rows are ordered by decreasing length (a.order): slot j takes row j of the first round of gridDim.x rows, row gridDim.x - 1 - j
     // of the second, ... (boustrophedon), so that every slot gets long and short rows alike -- in plain round-robin order slot 0 would
     // take the longest row of every round and the last slot the shortest (+-12 % of the mean at BASELINE configs[2])
+    const auto row_of = [&](unsigned it) { return it * gridDim.x + ((it & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x); };
+    const auto lookup = [&](unsigned row, int& b, int& ntok) {      // (one row ahead: see BwdChain)
+        b = 0; ntok = 0;
+        if (row < n) {
+            b = a1.order ? a1.order[row / a1.H] : (int)(row / a1.H);
+            ntok = a1.lens ? min(max(a1.lens[b], 0), a1.T) : a1.T;
+        }
+    };
+    int b_cur, ntok_cur;
+    lookup(row_of(0), b_cur, ntok_cur);
     for (unsigned it = 0; it * gridDim.x < n; ++it) {
-        const unsigned row = it * gridDim.x + ((it & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x);
+        const unsigned row = row_of(it);
         if (row >= n) continue;                                     // (the last round may be short; workgroup-uniform)
-        chunk_bwd12k_body<W_RAW, 1, false, true>(a1, row, blockIdx.x);
+        int b_nx, ntok_nx;
+        lookup(row_of(it + 1), b_nx, ntok_nx);
+        chunk_bwd12k_body<W_RAW, 1, false, true, false, true>(a1, row, blockIdx.x, BwdChain{b_cur, ntok_cur});
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's partial stores are out ...
         __syncthreads();                                            // ... and every wave's (the LDS tags are re-armed behind this barrier)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         ScanArgs a2 = a1;
         a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.gu = nullptr; a2.ckpt = ckpt2;
-        chunk_bwd12k_body<W_RAW, 2, false, true>(a2, row, blockIdx.x);
+        chunk_bwd12k_body<W_RAW, 2, false, true, false, true>(a2, row, blockIdx.x, BwdChain{b_cur, ntok_cur});
         __syncthreads();
+        b_cur = b_nx; ntok_cur = ntok_nx;
     }
 }
 
