@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Cycles of a call of the persistent wkv6_bi backward launch by role: whole body, inside the stage loop, outside it (a -DWKV6_STAMP build;
+    RWKV_AMD_LIB=build_ab/<stamp variant>/lib.so python tools/bi_stamps.py) -- profiles/r05_bi_call_overhead.txt."""
 import os, sys, ctypes
 import torch
 sys.path.insert(0, os.getcwd())
