@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FWD_BYTES, BWD_BYTES = 10, 18   # per token-channel
+GROUP_TOKENS, STAGE_TOKENS = 64, 32     # the forward kernel's loop unit (one workgroup barrier per 64-token group), the backward's (32-token stage)
 
 
 PMC_FILE = os.path.join(ROOT, "profiles", "r05_final_pmc.json")
@@ -307,6 +308,52 @@ def bench_dp_lora(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+PREWARM_MIN_S, PREWARM_MAX_S = 0.3, 2.0      # MI355X_MICROARCH.md, DVFS give-back item 6: sustained clocks need back-to-back launches
+PREWARM_BATCH, PREWARM_WINDOW = 8, 4         # convergence: the last 4 batches of 8 iterations (32 iterations) within 1 % of each other
+PREWARM_TOL = 0.01
+
+
+def prewarm_until_steady(fwd, bwd):
+    """Device pre-warm, outside both the W warm-up steps and the timed region: back-to-back fwd+bwd iterations until the mean iteration
+    time of the last PREWARM_WINDOW batches agrees within PREWARM_TOL (max - min over mean), at least PREWARM_MIN_S of device time and
+    at most PREWARM_MAX_S.  The queue never drains: the host waits for the end of batch n - 1 with batch n already enqueued, and on
+    return the last batch is still in flight, so the caller's next launch follows it without an idle gap.  Nothing is cached by it:
+    every iteration recomputes forward and backward from the same inputs."""
+    marks = [torch.cuda.Event(enable_timing=True)]
+    marks[0].record()
+    n, per_batch, total_ms, converged = 0, [], 0.0, False
+    while n < 100000:
+        for _ in range(PREWARM_BATCH):
+            fwd()
+            bwd()
+        n += 1
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[n].record()
+        if n < 2:
+            continue
+        marks[n - 1].synchronize()                      # batch n - 1 is done, batch n keeps the device busy
+        ms = marks[n - 2].elapsed_time(marks[n - 1])
+        per_batch.append(ms / PREWARM_BATCH)
+        total_ms += ms
+        last = per_batch[-PREWARM_WINDOW:]
+        spread = (max(last) - min(last)) / (sum(last) / len(last))
+        converged = len(last) == PREWARM_WINDOW and spread < PREWARM_TOL
+        if (converged and total_ms >= PREWARM_MIN_S * 1e3) or total_ms >= PREWARM_MAX_S * 1e3:
+            break
+    return {"prewarm_iters": n * PREWARM_BATCH, "prewarm_ms": round(total_ms, 1), "prewarm_converged": bool(converged),
+            "prewarm_first_ms_per_iter": round(per_batch[0], 4) if per_batch else None,
+            "prewarm_last_ms_per_iter": round(per_batch[-1], 4) if per_batch else None}
+
+
+def timed_launch_clocks(clocks, side, steps, launches_per_pass):
+    """In-kernel GHz of the timed steps' launches of one kernel (the last steps x launches_per_pass entries of the clock ring), one figure per
+    step (mean over the step's launches)."""
+    ghz = [g for g in clocks.get(side + "_ghz_launches", [])][-steps * launches_per_pass:]
+    if len(ghz) < steps * launches_per_pass or any(g is None for g in ghz):
+        return []
+    return [round(sum(ghz[i * launches_per_pass:(i + 1) * launches_per_pass]) / launches_per_pass, 3) for i in range(steps)]
+
+
 def build_workload(workload, dev, seed=0):
     """(fwd, bwd, tokens, B, T, H, name) of one of the operator-level workloads: closures over synthetic inputs resident in HBM."""
     from rwkv_lm_ext_amd import wkv6_op
@@ -383,13 +430,15 @@ def main():
                     help="roofline.traffic of the headline workload: measured now under rocprofv3 (N = 1), from the committed PMC file, or omitted")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks through torch.distributed.run also at --gpus 1 (the self-launch of `--gpus N`, on the box that exists)")
     ap.add_argument("--layers", type=int, default=24, help="dp_lora: number of RWKV blocks (1B6: 24)")
     ap.add_argument("--per-gpu-batch", type=int, default=32, help="dp_lora: triples per GPU and step")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args.workload)
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: spawn the ranks (nothing has touched the GPU yet) and relay
         import socket
         import subprocess
@@ -418,7 +467,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # the rank path -- RCCL process group, barrier in the fence, MAX all-reduce of the elapsed time -- runs whenever a rendezvous
+    # environment is present (torch.distributed.run sets it), also at world size 1: what a one-GPU box can execute of `--gpus N`
+    if world > 1 or all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -430,8 +481,14 @@ def main():
     C = H * 64
 
     from rwkv_lm_ext_amd.dp import timed_steps
+    # Everything the timed region needs exists BEFORE the pre-warm: events, the clock ring, the first use of every kernel (module load,
+    # LDS attributes, the library's device self-test).  Between the pre-warm, the W warm-up steps and the first timed step the host does
+    # nothing but launch: an idle gap of a few milliseconds re-arms the boost -> clamp -> recover transient of the power manager
+    # (profiles/r06_dvfs_transient.txt), which is worth +-20 % on a 14 ms window.
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     counter = {"i": -args.warmup}
+    launches_per_pass = 8 if args.workload == "infctx" else 1
+    ring = launches_per_pass * (args.steps + args.warmup + 8)
 
     def step():                       # HIP events on the launch stream bracket fwd and bwd of every timed step
         i = counter["i"]
@@ -445,25 +502,34 @@ def main():
         if i >= 0:
             ev[i][2].record()
 
-    # Device pre-warm, outside both the W warm-up steps and the timed region: the GPU needs tens of milliseconds of
-    # work to reach its sustained clocks (a 5-step warm-up is 4 ms), and the first launches pay module load / allocator
-    # costs.  Nothing is cached by it: every step recomputes forward and backward from the same inputs.
-    PREWARM = 64
-    for _ in range(PREWARM):
-        fwd()
-        bwd()
+    fwd()
+    bwd()
     torch.cuda.synchronize()
-    # in-run shader clock: wave 0 of every workgroup of the plain chunked kernels stamps {s_memtime, s_memrealtime} at its start and
-    # end (four scalar instructions and two 8-byte stores per workgroup and launch, inside the timed region like everything else)
-    probe = wkv6_op.ClockProbe(dev, n_slots=1024)
-    elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
-    clocks = probe.read()                 # the last forward / backward launch of the timed region
-    probe.close()
-    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    # in-run shader clock and duration of every launch of the warm-up and timed steps: wave 0 of the first 64 workgroups of the plain
+    # chunked kernels stamps {s_memtime, s_memrealtime} at its start and end (four scalar instructions and two 8-byte stores per
+    # workgroup and launch, inside the timed region like everything else) into a ring of the last `ring` launches per kernel
+    with wkv6_op.ClockProbe(dev, n_slots=64, n_launches=ring) as probe:
+        prewarm = prewarm_until_steady(fwd, bwd)
+        elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
+        clocks = probe.read()
+    fwd_steps = [e[0].elapsed_time(e[1]) for e in ev]
+    bwd_steps = [e[1].elapsed_time(e[2]) for e in ev]
+    fwd_ms = sum(fwd_steps) / args.steps
+    bwd_ms = sum(bwd_steps) / args.steps
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
+        fwd_ghz = timed_launch_clocks(clocks, "fwd", args.steps, launches_per_pass)
+        bwd_ghz = timed_launch_clocks(clocks, "bwd", args.steps, launches_per_pass)
+        seq_tokens = T // launches_per_pass                   # tokens one workgroup walks per launch
+
+        def mean_or_none(xs):
+            return round(sum(xs) / len(xs), 3) if xs else None
+
+        def cycles_per(ms, ghz, unit_tokens):
+            if not ghz or args.workload == "bi":              # (ragged rows, persistent slots: no fixed unit count per workgroup)
+                return None
+            return round(ms / launches_per_pass * 1e-3 * mean_or_none(ghz) * 1e9 / (seq_tokens / unit_tokens), 1)
         units = tokens * C                                    # token-channels per step per GPU
         dom_name, dom_ms, dom_b = ("backward", bwd_ms, BWD_BYTES) if bwd_ms >= fwd_ms else ("forward", fwd_ms, FWD_BYTES)
         dom_kernel = "chunk_fwd_kernel" if dom_name == "forward" else "chunk_bwd12k_kernel"
@@ -482,7 +548,7 @@ def main():
             else "WKV6 fwd+bwd tokens/sec/GPU (B=8,T=4096,C=2048) + %HBM roofline",
             "value": round(world * tokens * args.steps / elapsed, 1),
             "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_iters": PREWARM,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, **prewarm,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
@@ -490,10 +556,20 @@ def main():
                        "math": "split-bf16 (hi+lo) MFMA operands, fp32 accumulate and state",
                        "tokens_per_gpu": tokens, "channels": C,
                        "parallelism": f"dp{world} (independent batches per GPU, no data-path collective)",
+                       "rank_path": "nccl" if dist is not None else None,     # RCCL group + barrier + MAX all-reduce of the time executed
                        "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
-                       # in-kernel shader clock of the last timed launch of each kernel: d(s_memtime) / d(s_memrealtime) x 100 MHz,
-                       # median over workgroups (MI355X_MICROARCH.md, DVFS give-back item 6) -- for comparing numbers between boxes
-                       "fwd_clock_ghz": clocks.get("fwd_ghz"), "bwd_clock_ghz": clocks.get("bwd_ghz")},
+                       # every timed step by itself (HIP events on the launch stream): a steady state shows as flat lists
+                       "fwd_ms_steps": [round(x, 4) for x in fwd_steps], "bwd_ms_steps": [round(x, 4) for x in bwd_steps],
+                       "first_last_step_ratio": round((fwd_steps[-1] + bwd_steps[-1]) / (fwd_steps[0] + bwd_steps[0]), 4),
+                       # in-kernel shader clock of the timed launches of each kernel: d(s_memtime) / d(s_memrealtime) x 100 MHz, median
+                       # over workgroups (MI355X_MICROARCH.md, DVFS give-back item 6): mean over the timed steps, first and last step
+                       "fwd_clock_ghz": mean_or_none(fwd_ghz), "bwd_clock_ghz": mean_or_none(bwd_ghz),
+                       "fwd_clock_ghz_first_last": [fwd_ghz[0], fwd_ghz[-1]] if fwd_ghz else None,
+                       "bwd_clock_ghz_first_last": [bwd_ghz[0], bwd_ghz[-1]] if bwd_ghz else None,
+                       # kernel time in shader cycles per workgroup and unit of its loop (ms x in-run GHz / units): what a code change
+                       # changes; the clock is what the box and the power manager change
+                       "cycles_per_group": cycles_per(fwd_ms, fwd_ghz, GROUP_TOKENS),
+                       "cycles_per_stage": cycles_per(bwd_ms, bwd_ghz, STAGE_TOKENS)},
             "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4),

@@ -221,14 +221,19 @@ int wkv6_sigmul_backward(long n, const void* r, const void* kv, const void* dout
  * Returns 0 when it passes, WKV6_ESELFTEST (or the number of failed primitive checks) otherwise. */
 int wkv6_selftest(void* stream);
 /* Measurement aids (bench.py; no effect on results).
- * wkv6_set_clock_buffer: while `buf` (device memory, 2 * n_slots * 4 uint64) is set, wave 0 of the first n_slots workgroups of every
- * chunked forward launch writes {s_memtime, s_memrealtime} at its start and its end into buf[slot * 4 .. + 3], and of every chunked
- * backward launch into buf[(n_slots + slot) * 4 .. + 3]: the in-kernel shader clock of a launch is d(s_memtime) / d(s_memrealtime)
- * x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  buf = NULL (the default) switches it off: the kernels then execute one
- * scalar branch for it and no stamp.  Process-wide; not for use from concurrent streams.
+ * wkv6_set_clock_ring: while `buf` (device memory, 2 * n_launches * n_slots * 4 uint64) is set, wave 0 of the first n_slots workgroups of
+ * the n-th chunked forward launch since the call writes {s_memtime, s_memrealtime} at its start and its end into
+ * buf[((n % n_launches) * n_slots + slot) * 4 .. + 3], and of the n-th chunked backward launch into the second half of buf likewise:
+ * the in-kernel shader clock of a launch is d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6), its
+ * duration max(end s_memrealtime) - min(start s_memrealtime) over the slots.  buf = NULL (the default) switches it off: the kernels
+ * then execute one scalar branch for it and no stamp.  Process-wide; the caller keeps `buf` alive until it has switched the probe off.
+ * wkv6_set_clock_buffer(buf, n_slots) = wkv6_set_clock_ring(buf, n_slots, 1): every launch overwrites the one before it.
+ * wkv6_clock_ring_counts: chunked forward / backward launches since the ring was set.
  * wkv6_pass_marker: launches an empty kernel named wkv6::pass_marker_kernel on `stream`: a phase boundary in a profiler's
  * dispatch list. */
+void wkv6_set_clock_ring(void* buf, int n_slots, int n_launches);
 void wkv6_set_clock_buffer(void* buf, int n_slots);
+void wkv6_clock_ring_counts(long* fwd, long* bwd);
 int wkv6_pass_marker(void* stream);
 /* "major.minor" of the library. */
 const char* wkv6_amd_version(void);

@@ -59,7 +59,9 @@ SIGNATURES = {
     "wkv6_sigmul_forward": (_I, [_L] + [_VP] * 4),
     "wkv6_sigmul_backward": (_I, [_L] + [_VP] * 6),
     "wkv6_selftest": (_I, [_VP]),
+    "wkv6_set_clock_ring": (None, [_VP, _I, _I]),
     "wkv6_set_clock_buffer": (None, [_VP, _I]),
+    "wkv6_clock_ring_counts": (None, [ctypes.POINTER(_L), ctypes.POINTER(_L)]),
     "wkv6_pass_marker": (_I, [_VP]),
     "wkv6_amd_version": (ctypes.c_char_p, []),
 }
@@ -72,8 +74,17 @@ EUNSUPPORTED = -4
 ERRORS = {-1: "WKV6_EINVAL (shape: need C == H*64 and B,T,C,H >= 1)", -2: "WKV6_ENULL (null pointer)",
           -3: "WKV6_EWORKSPACE (workspace too small / allocation failed)", -4: "WKV6_EUNSUPPORTED"}
 
+# measurement aids: an explicit A/B library of an earlier round (RWKV_AMD_LIB) may lack them; has_symbol() says which are there
+MEASUREMENT_AIDS = ("wkv6_set_clock_ring", "wkv6_set_clock_buffer", "wkv6_clock_ring_counts", "wkv6_pass_marker")
+
 _lib = None
+_missing = set()
 _lock = threading.Lock()
+
+
+def has_symbol(name):
+    load()
+    return name not in _missing
 
 
 def lib_path():
@@ -95,8 +106,9 @@ def load():
             lib = ctypes.CDLL(path)
             explicit = bool(os.environ.get("RWKV_AMD_LIB"))
             for name, (res, args) in SIGNATURES.items():
-                if explicit and name in ("wkv6_set_clock_buffer", "wkv6_pass_marker") and not hasattr(lib, name):
-                    continue                     # an A/B library of an earlier round: the measurement aids are newer than it
+                if explicit and name in MEASUREMENT_AIDS and not hasattr(lib, name):
+                    _missing.add(name)           # an A/B library of an earlier round: the measurement aids are newer than it
+                    continue
                 fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
                 fn.restype = res
                 fn.argtypes = args

@@ -328,19 +328,46 @@ extern "C" void wkv6_set_debug_buffer(void* p) { wkv6::g_stamp_buffer = reinterp
 #endif
 
 namespace wkv6 {
-unsigned long long* g_clock_buffer = nullptr;
-int g_clock_slots = 0;
-namespace { __global__ void pass_marker_kernel() {} }
+namespace {
+__global__ void pass_marker_kernel() {}
+// the clock ring: [2 kinds][n_launches][n_slots][4] uint64 of caller-owned device memory; the launchers of one process may run on
+// several threads (the autograd engine's), so the ring's description and the launch counts are read and advanced under a lock
+struct ClockRing {
+    std::mutex mu;
+    unsigned long long* buf = nullptr;
+    int slots = 0, launches = 0;
+    long count[2] = {0, 0};
+} g_clock;
+}
+unsigned long long* clock_claim(int kind, int* slots)
+{
+    std::lock_guard<std::mutex> lk(g_clock.mu);
+    *slots = g_clock.slots;
+    if (!g_clock.buf) return nullptr;
+    const long n = g_clock.count[kind]++;
+    return g_clock.buf + ((size_t)kind * g_clock.launches + (size_t)(n % g_clock.launches)) * g_clock.slots * 4;
+}
 }
 
 extern "C" {
 
 const char* wkv6_amd_version(void) { return "0.1"; }
 
-void wkv6_set_clock_buffer(void* buf, int n_slots)
+void wkv6_set_clock_ring(void* buf, int n_slots, int n_launches)
 {
-    wkv6::g_clock_buffer = (buf && n_slots > 0) ? reinterpret_cast<unsigned long long*>(buf) : nullptr;
-    wkv6::g_clock_slots = wkv6::g_clock_buffer ? n_slots : 0;
+    std::lock_guard<std::mutex> lk(wkv6::g_clock.mu);
+    const bool on = buf && n_slots > 0 && n_launches > 0;
+    wkv6::g_clock.buf = on ? reinterpret_cast<unsigned long long*>(buf) : nullptr;
+    wkv6::g_clock.slots = on ? n_slots : 0;
+    wkv6::g_clock.launches = on ? n_launches : 0;
+    wkv6::g_clock.count[0] = wkv6::g_clock.count[1] = 0;
+}
+void wkv6_set_clock_buffer(void* buf, int n_slots) { wkv6_set_clock_ring(buf, n_slots, 1); }
+void wkv6_clock_ring_counts(long* fwd, long* bwd)
+{
+    std::lock_guard<std::mutex> lk(wkv6::g_clock.mu);
+    if (fwd) *fwd = wkv6::g_clock.count[0];
+    if (bwd) *bwd = wkv6::g_clock.count[1];
 }
 int wkv6_pass_marker(void* stream)
 {

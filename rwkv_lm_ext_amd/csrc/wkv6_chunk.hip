@@ -39,6 +39,9 @@ namespace {
 
 using namespace chunk;
 
+#ifndef WKV6_FWD_PAIR
+#define WKV6_FWD_PAIR 0                     // role -> SIMD pairing of the forward's waves (chunk_fwd_body)
+#endif
 constexpr int GRP_BYTES = NBLK * BLK_BYTES;
 constexpr int CKX_BYTES = 4 * 4096;         // checkpoint transposition buffers of the four consumers (row order: wkv6_scan.h)
 // y leaves through LDS as whole token rows.  A consumer's result tile is 16 tokens x 16 channels = 32-byte pieces of the [B, T, C]
@@ -111,6 +114,8 @@ struct FwdChain {
     int nx_b, nx_ntok;
     bool nx_rev, nx_use_u;         // reversed / with the bonus vector
 };
+// (unsplit launches) does hardware wave `hw` of a workgroup play a producer?  One definition: chunk_fwd_body's role map below
+__device__ __forceinline__ bool fwd_hw_wave_produces(int hw) { return WKV6_FWD_PAIR == 1 ? (hw & 3) < 2 : hw >= 4; }
 template <bool W_RAW, bool STATE_ONLY, bool ACC, bool GN, bool AFF, bool CLK = false, bool CHAIN = false>
 __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned slot, const unsigned sslot, FwdRaw& raw, const FwdChain& ch = FwdChain{})
 {
@@ -125,7 +130,27 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
     // producer w - 2 (wave id 4 + w - 2) otherwise.  The preparation is duplicated, on CUs that would otherwise idle.
     const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform, provably so
     const int part = a.split ? (int)(slot & 1) : 0, bh = a.split ? (int)(slot >> 1) : (int)slot;
-    const int wid = a.split ? (hwid < 2 ? 2 * part + hwid : hwid + 2) : hwid;
+    // Role -> hardware wave.  The waves of a workgroup go to the CU's four SIMDs round-robin (hardware waves w and w + 4 share one:
+    // profiles/r06_fwd_pairing.txt has the HW_ID read-back).  WKV6_FWD_PAIR = 0: waves 0..3 consume, 4..7 produce -- one producer and one
+    // consumer per SIMD.  1: the roles are paired with themselves -- two SIMDs host two producers each, two host two consumers each (split
+    // launches, 6 waves: the two consumers share a SIMD, two producers share one, two have a SIMD to themselves).  cidx: the consumer's
+    // index within its workgroup (its LDS regions, its rows of a y flush, its stagger).
+    int wid, cidx;
+#if WKV6_FWD_PAIR == 1
+    {
+        const int simd = hwid & 3, second = hwid >> 2;
+        if (a.split) {
+            cidx = second;                                               // (consumers: hardware waves 0 and 4)
+            wid = simd == 0 ? 2 * part + second : (simd == 1 ? 4 + second : 4 + simd);   // producers: waves 1, 5 -> blocks 0, 1; 2 -> 2; 3 -> 3
+        } else {
+            cidx = 2 * (simd - 2) + second;                              // (consumers: hardware waves 2, 6, 3, 7)
+            wid = simd < 2 ? 4 + 2 * simd + second : cidx;               // producers: waves 0, 4, 1, 5 -> blocks 0, 1, 2, 3
+        }
+    }
+#else
+    wid = a.split ? (hwid < 2 ? 2 * part + hwid : hwid + 2) : hwid;
+    cidx = hwid;
+#endif
     const bool producer = wid >= 4;
     const int wv = wid & 3;                                          // block (producer) / column tile (consumer)
     // (CHAIN: the persistent launch has looked the row's batch index and length up -- two dependent memory round trips -- a call ahead)
@@ -404,7 +429,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         // (one launch for both halves, chunk_fwd_bi_kernel: the fp32 side buffer is this workgroup slot's own scratch, [T][64] with a
         // token stride of 64)
         const unsigned ystr = a.side_compact ? (unsigned)HEAD : (unsigned)a.C;
-        const unsigned ych = a.side_compact ? 16u * (unsigned)hwid : 16u * (unsigned)wv;             // this consumer's channels in a side row
+        const unsigned ych = a.side_compact ? 16u * (unsigned)cidx : 16u * (unsigned)wv;             // this consumer's channels in a side row
         const rsrc_t rs_yf = make_rsrc(a.y_f32 ? a.y_f32 + (a.side_compact ? (long)sslot * a.T * HEAD : base) : nullptr,
                                        (a.y_f32 && !STATE_ONLY && ntok > 0) ? (unsigned)(ntok - 1) * ystr * 4u + 256u : 0u);
         // lane parts of this consumer's result tile (token x of a block, channels 16 wv + 4 g ..) in y and in the fp32 side buffer
@@ -439,16 +464,16 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         uint2 gn_g[NBLK];
         unsigned gn_off[NBLK];
         char* const gn_stat = smem + 2 * GRP_BYTES;
-        char* const ckx = smem + 2 * GRP_BYTES + (GN ? 4096 : 0) + hwid * 4096;   // this consumer's checkpoint transposition buffer
+        char* const ckx = smem + 2 * GRP_BYTES + (GN ? 4096 : 0) + cidx * 4096;   // this consumer's checkpoint transposition buffer
         // staged y rows (see YRS): consumer hardware wave c = hwid of the workgroup's ncw = 4 (2 in split mode) owns bytes 32 c .. + 31
         // of a row piece of 32 ncw bytes and, at the flush, rows (64 / ncw) c .. of the group
         char* const ys = smem + 2 * GRP_BYTES + (GN ? 4096 : 0) + CKX_BYTES;
         const int ylsh = a.split ? 2 : 3;                          // log2(lanes per staged row piece: 16-byte chunks)
         auto stage_y = [&](int grp_, int blk, uint2 yb) {
-            *reinterpret_cast<uint2*>(ys + (grp_ & 1) * YS_BYTES + (BLK * blk + x) * YRS + 32 * hwid + 8 * g) = yb;
+            *reinterpret_cast<uint2*>(ys + (grp_ & 1) * YS_BYTES + (BLK * blk + x) * YRS + 32 * cidx + 8 * g) = yb;
         };
         const int fl_chunk = lane & ((1 << ylsh) - 1);
-        const int fl_row[2] = {(GRP >> (ylsh - 1)) * hwid + (lane >> ylsh), (GRP >> (ylsh - 1)) * hwid + (64 >> ylsh) + (lane >> ylsh)};
+        const int fl_row[2] = {(GRP >> (ylsh - 1)) * cidx + (lane >> ylsh), (GRP >> (ylsh - 1)) * cidx + (64 >> ylsh) + (lane >> ylsh)};
         const int lp_fl[2] = {tok.lane(fl_row[0], 32 * part + 8 * fl_chunk, C_), tok.lane(fl_row[1], 32 * part + 8 * fl_chunk, C_)};
         auto flush_y = [&](int grp_) {     // after the barrier that closed group grp_: every consumer's pieces of it are in the image
 #pragma unroll
@@ -502,7 +527,7 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
             // collide (nor with the producers' stores), the delay comes out of the barrier wait.  Same box: forward -2.7 % (0.2198 ->
             // 0.2137 ms; 128 or 448 cycles per wave -0.8 / -1.5 %; staggering the producers too +1.2 ... 2 %: profiles/r05_stagger.txt);
             // 192 cycles per wave since the end of round 5 (another -3.4 % after the producers' path had been shortened).
-            for (int i_ = 0; i_ < hwid; ++i_) __builtin_amdgcn_s_sleep(CONSUMER_STAGGER);   // (hwid: the consumer's index within its workgroup)
+            for (int i_ = 0; i_ < cidx; ++i_) __builtin_amdgcn_s_sleep(CONSUMER_STAGGER);   // (cidx: the consumer's index within its workgroup)
             if (staged && grp > 0) flush_y(grp - 1);
             if constexpr (ACC) acc_request(grp + 1, acc_nxt);     // (past the last group: past the end of the resource, reads zero)
 
@@ -690,6 +715,9 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
         unsigned long long* const d = reinterpret_cast<unsigned long long*>(a.aux) + ((long)bh * 16 + wid) * 8;
 #ifdef WKV6_STAMP
         for (int i = 0; i < 6; ++i) d[i] = stamp_acc[i];
+#else
+        // which SIMD the wave ran on: HW_REG_HW_ID (wave_id 3:0, simd_id 5:4, pipe_id 7:6, cu_id 11:8, sh_id 12, se_id 15:13) | hardware wave << 32
+        d[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)hwid << 32);
 #endif
         d[6] = clk1 - clk0;
         d[7] = rtc1 - rtc0;
@@ -736,7 +764,7 @@ __global__ __launch_bounds__(512) void chunk_fwd_bi_kernel(const ScanArgs a1, fl
     // FwdRaw above.  The producer waves write no global memory and take no part in the fences between the halves, which would make them
     // wait for those requests.)
     FwdRaw raw;
-    const bool producer_wave = (threadIdx.x >> 6) >= 4;
+    const bool producer_wave = fwd_hw_wave_produces((int)(threadIdx.x >> 6));
     // a row's batch index and length: a.order[row / H] -> a.lens[b], two dependent memory round trips that used to open every call; looked up
     // one row ahead here
     const auto row_of = [&](unsigned it) { return it * gridDim.x + ((it & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x); };
@@ -805,7 +833,7 @@ hipError_t launch_chunk_fwd(const ScanArgs& a_, hipStream_t st)
     if (!offsets_fit(a_)) return hipErrorInvalidValue;
     ScanArgs a = a_;
     a.split = want_split(a.B * a.H);
-    a.clk = g_clock_buffer; a.clk_slots = g_clock_slots;
+    a.clk = clock_claim(0, &a.clk_slots);
 #ifdef WKV6_DEBUGBUF
     a.aux = reinterpret_cast<float*>(g_stamp_buffer);
 #endif

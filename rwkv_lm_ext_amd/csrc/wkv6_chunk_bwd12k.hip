@@ -1344,7 +1344,7 @@ hipError_t launch_chunk_bwd12k(const ScanArgs& a_, hipStream_t st)
     if (!a_.ckpt) return hipErrorInvalidValue;
     if (a_.split && (a_.g_in || a_.rc_in)) return hipErrorInvalidValue;     // (segment rows of a two-level scan run one workgroup each)
     ScanArgs a = a_;
-    a.clk = g_clock_buffer ? g_clock_buffer + (size_t)g_clock_slots * 4 : nullptr; a.clk_slots = g_clock_slots;
+    a.clk = clock_claim(1, &a.clk_slots);
 #ifdef WKV6_DEBUGBUF
     a.aux = reinterpret_cast<float*>(g_stamp_buffer);
 #endif

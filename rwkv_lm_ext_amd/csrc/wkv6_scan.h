@@ -165,8 +165,9 @@ int bi_slots(int BH);                        // workgroup slots such a launch us
 hipError_t launch_chunk_bwd12k(const ScanArgs& a, hipStream_t st);    // reverse pass over 64-token row-order checkpoints, a.split as given (wkv6_chunk_bwd12k.hip)
 size_t chunk_ckpt_floats(int B, int T, int H);
 hipError_t launch_chunk_state_pass(const ScanArgs& a, hipStream_t st);   // state recurrence only (s_out, ckpt, dsum)
-extern unsigned long long* g_clock_buffer;   // wkv6_set_clock_buffer (wkv6_api.hip)
-extern int g_clock_slots;
+// In-run clock probe (wkv6_set_clock_ring, wkv6_api.hip): where launch number n of kind (0: chunked forward, 1: chunked backward) stamps,
+// or null; takes the launch's place in the ring (host side, one atomic increment per launch)
+unsigned long long* clock_claim(int kind, int* slots);
 int cu_count();
 int want_split(int BH);                      // two workgroups per (batch, head)?  (wkv6_chunk_bwd12k.hip)
 

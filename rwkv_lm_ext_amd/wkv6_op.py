@@ -485,32 +485,104 @@ def selftest():
 
 
 def pass_marker():
-    """Launch the empty kernel wkv6::pass_marker_kernel on the current stream (a phase boundary in a profiler's dispatch list)."""
-    _lib.check(_lib.load().wkv6_pass_marker(_stream_ptr()), "wkv6_pass_marker")
+    """Launch the empty kernel wkv6::pass_marker_kernel on the current stream (a phase boundary in a profiler's dispatch list).
+    A no-op with an explicit A/B library (RWKV_AMD_LIB) that predates the symbol."""
+    if _lib.has_symbol("wkv6_pass_marker"):
+        _lib.check(_lib.load().wkv6_pass_marker(_stream_ptr()), "wkv6_pass_marker")
 
 
 class ClockProbe:
-    """In-run shader clock of the chunked kernels (wkv6_set_clock_buffer, include/wkv6_amd.h): while active, wave 0 of the first
-    `n_slots` workgroups of every chunked forward / backward launch stamps {s_memtime, s_memrealtime} at its start and end.
-    read() -> {"fwd_ghz", "bwd_ghz"}: median over the workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz for the LAST launch of
-    each kernel (None where nothing was stamped)."""
+    """In-run shader clock and duration of the chunked kernels' launches (wkv6_set_clock_ring, include/wkv6_amd.h): while active, wave 0
+    of the first `n_slots` workgroups of every chunked forward / backward launch stamps {s_memtime, s_memrealtime} at its start and end
+    into a ring of the last `n_launches` launches of each kind.
 
-    def __init__(self, device, n_slots=256):
-        self.n = n_slots
-        self.buf = torch.zeros(2 * n_slots * 4, dtype=torch.int64, device=device)
-        _lib.load().wkv6_set_clock_buffer(self.buf.data_ptr(), n_slots)
+        with ClockProbe(dev, n_slots=64, n_launches=4096) as probe:
+            ... launches ...
+            rec = probe.read()
+
+    read() -> {"fwd_ghz", "bwd_ghz"} (median over the workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz for the LAST launch of
+    each kind, None where nothing was stamped) plus, per kind, the lists "fwd_ghz_launches" / "fwd_us_launches" (oldest first: every
+    launch still in the ring; us = max(end) - min(start) of s_memrealtime over the stamped workgroups) and "fwd_count".
+    The probe owns the device buffer for as long as the library holds its address: close() (also on __exit__ / __del__) switches the
+    stamps off first.  With an explicit A/B library (RWKV_AMD_LIB) that predates the symbols everything is a no-op and read() returns
+    None values."""
+
+    def __init__(self, device, n_slots=256, n_launches=1):
+        self.n, self.nl = int(n_slots), int(n_launches)
+        self.lib = _lib.load()
+        self.ring = _lib.has_symbol("wkv6_set_clock_ring")
+        self.active = self.ring or _lib.has_symbol("wkv6_set_clock_buffer")
+        self.buf = None
+        if not self.active:
+            return
+        if not self.ring:
+            self.nl = 1
+        self.buf = torch.zeros(2 * self.nl * self.n * 4, dtype=torch.int64, device=device)
+        if self.ring:
+            self.lib.wkv6_set_clock_ring(self.buf.data_ptr(), self.n, self.nl)
+        else:
+            self.lib.wkv6_set_clock_buffer(self.buf.data_ptr(), self.n)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counts(self):
+        if not (self.active and self.ring):
+            return None, None
+        import ctypes
+        f, b = ctypes.c_long(0), ctypes.c_long(0)
+        self.lib.wkv6_clock_ring_counts(ctypes.byref(f), ctypes.byref(b))
+        return f.value, b.value
 
     def read(self):
-        d = self.buf.view(2, self.n, 4).cpu().double()
         out = {}
-        for i, name in enumerate(("fwd_ghz", "bwd_ghz")):
-            dc, dr = d[i, :, 2] - d[i, :, 0], d[i, :, 3] - d[i, :, 1]
-            ok = (dr > 0) & (d[i, :, 0] > 0)
-            out[name] = round(float((dc[ok] / dr[ok]).median()) * 0.1, 3) if bool(ok.any()) else None
+        names = ("fwd", "bwd")
+        if not self.active or self.buf is None:
+            for nm in names:
+                out[nm + "_ghz"] = None
+                out[nm + "_ghz_launches"], out[nm + "_us_launches"], out[nm + "_count"] = [], [], None
+            return out
+        d = self.buf.view(2, self.nl, self.n, 4).cpu().double()
+        cnt = self.counts()
+        for i, nm in enumerate(names):
+            n = cnt[i]
+            if n is None:                       # plain buffer (no ring in the library): one launch, the last
+                order = [0]
+            else:
+                order = [j % self.nl for j in range(max(0, n - self.nl), n)]
+            ghz, us = [], []
+            for j in order:
+                s = d[i, j]
+                dc, dr = s[:, 2] - s[:, 0], s[:, 3] - s[:, 1]
+                ok = (dr > 0) & (s[:, 0] > 0)
+                if bool(ok.any()):
+                    ghz.append(round(float((dc[ok] / dr[ok]).median()) * 0.1, 3))
+                    us.append(round(float(s[ok, 3].max() - s[ok, 1].min()) * 0.01, 2))
+                else:
+                    ghz.append(None)
+                    us.append(None)
+            out[nm + "_ghz_launches"], out[nm + "_us_launches"], out[nm + "_count"] = ghz, us, n
+            out[nm + "_ghz"] = ghz[-1] if ghz else None
         return out
 
     def close(self):
-        _lib.load().wkv6_set_clock_buffer(None, 0)
+        if getattr(self, "buf", None) is None:
+            return
+        if self.ring:
+            self.lib.wkv6_set_clock_ring(None, 0, 0)
+        else:
+            self.lib.wkv6_set_clock_buffer(None, 0)
+        self.buf = None
 
 
 # ---- torch.ops registration: the TORCH_LIBRARY(wkv6|wkv6bi|wkv6state|wkv6infctx, m) blocks ------------

@@ -58,16 +58,40 @@ class Mode:
         hi = round_bits(x, bits)
         return [hi, round_bits(np.asarray(x, np.float64) - hi, bits)]
 
-    def mm(self, a, b, a_exact=False, b_exact=False):
-        """a @ b with the policy applied to the inexact operands; hi*hi + hi*lo + lo*hi for two-piece operands."""
-        pa = [np.asarray(a, np.float64)] if a_exact else self.pieces(a)
-        pb = [np.asarray(b, np.float64)] if b_exact else self.pieces(b)
+    def mm(self, a, b, a_exact=False, b_exact=False, ca=None, cb=None):
+        """a @ b with the policy applied to the inexact operands; hi*hi + hi*lo + lo*hi for two-piece operands.
+        ca / cb: the operand class of a / b (OPERAND_CLASSES) -- a per-class policy (PerOperand) rounds each class its own way."""
+        pa = [np.asarray(a, np.float64)] if a_exact else self.pieces_of(a, ca)
+        pb = [np.asarray(b, np.float64)] if b_exact else self.pieces_of(b, cb)
         out = 0.0
         for i, x in enumerate(pa):
             for j, y in enumerate(pb):
                 if i + j <= 1:                       # lo*lo is dropped, as in the kernels
                     out = out + x @ y
         return out
+
+
+OPERAND_CLASSES = ("Rhat", "Khat", "scores", "dA", "E8.S", "E16m8.G")     # every fp32-derived MFMA operand of the two kernels
+
+
+def _pieces_of(self, x, cls):
+    return self.pieces(x)
+
+
+Mode.pieces_of = _pieces_of
+
+
+class PerOperand(Mode):
+    """ONE operand class rounded the candidate way (`fp16`: 11 bits at any exponent, `bf16`: 8 bits), every other class split bf16 hi + lo
+    as the kernels do: would that class's split instructions and two of its three MFMAs be removable without touching the contract?"""
+
+    def __init__(self, cls, candidate):
+        super().__init__(f"{cls}:{candidate}")
+        self.cls, self.cand, self.rest = cls, Mode(candidate), Mode("split")
+
+    def pieces_of(self, x, cls):
+        assert cls in OPERAND_CLASSES, cls
+        return (self.cand if cls == self.cls else self.rest).pieces(x)
 
 
 def block_factors(w):
@@ -94,9 +118,9 @@ def forward(mode, r, k, v, w, u, s0=None):
         _, lw, c, c8, c16 = block_factors(wb)
         Rh = rb * np.exp(c[:n] - c8)
         Kh = kb * np.exp(c8 - c[1:n + 1])
-        A = np.tril(mode.mm(Rh, Kh.T), -1) + np.diag(np.sum(rb * u * kb, 1))      # masked scores + bonus diagonal
-        y[sl] = mode.mm(A, vb, b_exact=True) + mode.mm(Rh, np.exp(c8)[:, None] * S)
-        S = np.exp(c16)[:, None] * S + np.exp(c16 - c8)[:, None] * mode.mm(Kh.T, vb, b_exact=True)
+        A = np.tril(mode.mm(Rh, Kh.T, ca="Rhat", cb="Khat"), -1) + np.diag(np.sum(rb * u * kb, 1))      # masked scores + bonus diagonal
+        y[sl] = mode.mm(A, vb, b_exact=True, ca="scores") + mode.mm(Rh, np.exp(c8)[:, None] * S, ca="Rhat", cb="E8.S")
+        S = np.exp(c16)[:, None] * S + np.exp(c16 - c8)[:, None] * mode.mm(Kh.T, vb, b_exact=True, ca="Khat")
     return y, states, S
 
 
@@ -120,11 +144,11 @@ def backward(mode, r, k, v, w, u, gy, states):
         E8, E16, E16m8 = np.exp(c8), np.exp(c16), np.exp(c16 - c8)
         dA = np.tril(gb @ vb.T, -1)                                               # exact operands
         vg = np.sum(gb * vb, 1)
-        A = np.tril(mode.mm(Rh, Kh.T), -1) + np.diag(np.sum(rb * u * kb, 1))
+        A = np.tril(mode.mm(Rh, Kh.T, ca="Rhat", cb="Khat"), -1) + np.diag(np.sum(rb * u * kb, 1))
         GE = E16m8[:, None] * G
-        gv[sl] = mode.mm(A.T, gb, b_exact=True) + mode.mm(Kh, GE)
-        dq = fR * (mode.mm(dA, Kh) + E8 * mode.mm(gb, S.T, a_exact=True))          # (E8 applied to the result, as the kernel does)
-        dk = fK * (mode.mm(dA.T, Rh) + mode.mm(vb, GE.T, a_exact=True))
+        gv[sl] = mode.mm(A.T, gb, b_exact=True, ca="scores") + mode.mm(Kh, GE, ca="Khat", cb="E16m8.G")
+        dq = fR * (mode.mm(dA, Kh, ca="dA", cb="Khat") + E8 * mode.mm(gb, S.T, a_exact=True, cb="E8.S"))   # (E8 applied to the result, as the kernel does)
+        dk = fK * (mode.mm(dA.T, Rh, ca="dA", cb="Rhat") + mode.mm(vb, GE.T, a_exact=True, cb="E16m8.G"))
         gr[sl] = dq + vg[:, None] * u * kb
         gk[sl] = dk + vg[:, None] * u * rb
         gu += np.sum(vg[:, None] * rb * kb, 0)
@@ -135,7 +159,7 @@ def backward(mode, r, k, v, w, u, gy, states):
         lwn = lw_true * np.exp(np.minimum(lw_true - LW_MIN, 0.0))
         gw[sl] = (Rc + (sfx - dl) - bt) * lwn
         Rc = Rc + sfx[0]
-        G = E16[:, None] * G + E8[:, None] * mode.mm(Rh.T, gb, b_exact=True)
+        G = E16[:, None] * G + E8[:, None] * mode.mm(Rh.T, gb, b_exact=True, ca="Rhat")
     return gr, gk, gv, gw, gu
 
 
@@ -176,7 +200,8 @@ def run(T=1024, heads=4, kinds=("init", "stress"), modes=("split", "fp16x2", "fp
         r, k, v, w, u, gy = synth(T, heads, kind)
         outs = {}
         for name in ("exact",) + tuple(modes):
-            m = Mode(name)
+            m = name if isinstance(name, Mode) else Mode(name)
+            name = m.name
             acc = {n: [] for n in ("y", "gr", "gk", "gv", "gw", "gu")}
             for h in range(heads):
                 s = slice(64 * h, 64 * h + 64)
@@ -186,7 +211,7 @@ def run(T=1024, heads=4, kinds=("init", "stress"), modes=("split", "fp16x2", "fp
                 for n, val in zip(acc, (y,) + g):
                     acc[n].append(val)
             outs[name] = {n: np.concatenate([np.atleast_2d(x) for x in vals], -1) for n, vals in acc.items()}
-        for name in modes:
+        for name in (m.name if isinstance(m, Mode) else m for m in modes):
             for n in ("y", "gr", "gk", "gv", "gw"):
                 rms, off, ulps = report(outs[name][n], outs["exact"][n], floor=0.1 if n == "gw" else 1e-3)
                 ok = rms <= 1e-3 and ulps <= 2.0 and off <= (0.10 if n == "gw" else 0.05)
@@ -198,12 +223,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--T", type=int, default=1024)
     ap.add_argument("--heads", type=int, default=4)
+    ap.add_argument("--per-operand", action="store_true",
+                    help="ONE operand class at a time in fp16 / plain bf16, the rest split (profiles/r06_ceiling.md)")
     args = ap.parse_args()
-    rows = run(args.T, args.heads)
+    modes = ("split", "fp16x2", "fp16", "bf16")
+    if args.per_operand:
+        modes = ("split",) + tuple(PerOperand(c, cand) for cand in ("fp16", "bf16") for c in OPERAND_CLASSES)
+    rows = run(args.T, args.heads, modes=modes)
     print(f"# T = {args.T}, {args.heads} heads; contract: rel-rms <= 1e-3, <= 2 ulp, >= 95 % correctly rounded (gw: >= 90 % at long T, as the suite)")
-    print(f"{'decays':8s} {'operands':8s} {'tensor':6s} {'rel-rms':>10s} {'% not correctly rounded':>24s} {'max ulp':>8s}  contract")
+    print(f"{'decays':8s} {'operands':14s} {'tensor':6s} {'rel-rms':>10s} {'% not correctly rounded':>24s} {'max ulp':>8s}  contract")
     for kind, name, n, rms, off, ulps, ok in rows:
-        print(f"{kind:8s} {name:8s} {n:6s} {rms:10.2e} {100 * off:24.1f} {ulps:8.2f}  {'pass' if ok else 'FAIL'}")
+        print(f"{kind:8s} {name:14s} {n:6s} {rms:10.2e} {100 * off:24.1f} {ulps:8.2f}  {'pass' if ok else 'FAIL'}")
+    if args.per_operand:
+        print("# summary: does the class stay inside the contract on every tensor (both decay regimes)?  worst % not correctly rounded / worst ulp")
+        for m in modes[1:]:
+            mine = [r for r in rows if r[1] == m.name and r[2] != "gw"]
+            gw = [r for r in rows if r[1] == m.name and r[2] == "gw"]
+            print(f"#   {m.name:14s} y/gr/gk/gv: {'pass' if all(r[6] for r in mine) else 'FAIL'} ({100 * max(r[4] for r in mine):.1f} %, {max(r[5] for r in mine):.2f} ulp)"
+                  f"   gw: {'pass' if all(r[6] for r in gw) else 'FAIL'} ({100 * max(r[4] for r in gw):.1f} %, {max(r[5] for r in gw):.2f} ulp)")
 
 
 if __name__ == "__main__":

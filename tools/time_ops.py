@@ -42,11 +42,31 @@ def run(fn, n):
 
 fwd = lambda: wkv6_op.forward_ex(r, k, v, w, u, H, y=y, ckpt=None if args.no_ckpt else ckpt)
 bwd = lambda: wkv6_op.backward_ex(r, k, v, w, u, gy, H, ckpt=ckpt)
-for _ in range(30):
-    fwd()
-    if args.only != "fwd":
-        bwd()
+import time as _time
+_t0 = _time.perf_counter()
+while _time.perf_counter() - _t0 < float(os.environ.get("WKV6_PREWARM_S", "0.6")):     # sustained clocks first (profiles/r06_dvfs_transient.txt)
+    for _ in range(16):
+        fwd()
+        if args.only != "fwd":
+            bwd()
+    torch.cuda.synchronize()
 out = {}
+if args.only == "both" and os.environ.get("WKV6_CLOCKS", "0") == "1":
+    # inside fwd+bwd steps, launch by launch from the clock ring (what bench.py times): mean duration, clock and cycles per loop unit
+    n = 4 * args.iters
+    with wkv6_op.ClockProbe(dev, n_slots=64, n_launches=n) as ring:
+        for _ in range(n):
+            fwd()
+            bwd()
+        torch.cuda.synchronize()
+        rec = ring.read()
+    for side, unit in (("fwd", 64), ("bwd", 32)):
+        us, ghz = rec[side + "_us_launches"], rec[side + "_ghz_launches"]
+        if us and None not in us:
+            m_us, m_ghz = sum(us) / len(us), sum(ghz) / len(ghz)
+            out[f"step_{side}_us"] = round(m_us, 1)
+            out[f"step_{side}_ghz"] = round(m_ghz, 3)
+            out[f"step_{side}_cyc_per_{unit}tok"] = round(m_us * m_ghz * 1e3 / ((T + unit - 1) // unit))
 probe = wkv6_op.ClockProbe(dev, n_slots=B * H) if os.environ.get("WKV6_CLOCKS", "0") == "1" else None   # in-run shader clocks (plain kernels)
 if args.only in ("both", "fwd"):
     out["fwd_ms"] = round(run(fwd, args.iters), 4)
