@@ -345,13 +345,14 @@ def prewarm_until_steady(fwd, bwd):
             "prewarm_last_ms_per_iter": round(per_batch[-1], 4) if per_batch else None}
 
 
-def timed_launch_clocks(clocks, side, steps, launches_per_pass):
-    """In-kernel GHz of the timed steps' launches of one kernel (the last steps x launches_per_pass entries of the clock ring), one figure per
-    step (mean over the step's launches)."""
-    ghz = [g for g in clocks.get(side + "_ghz_launches", [])][-steps * launches_per_pass:]
-    if len(ghz) < steps * launches_per_pass or any(g is None for g in ghz):
+def timed_launch_clocks(clocks, side, steps, launches_per_pass, what="ghz"):
+    """In-kernel GHz (what = "ghz": mean over the step's launches) or kernel-only duration in ms (what = "us": sum over them) of the timed
+    steps' launches of one kernel: the last steps x launches_per_pass entries of the clock ring, one figure per step."""
+    xs = [g for g in clocks.get(f"{side}_{what}_launches", [])][-steps * launches_per_pass:]
+    if len(xs) < steps * launches_per_pass or any(g is None for g in xs):
         return []
-    return [round(sum(ghz[i * launches_per_pass:(i + 1) * launches_per_pass]) / launches_per_pass, 3) for i in range(steps)]
+    per = [sum(xs[i * launches_per_pass:(i + 1) * launches_per_pass]) for i in range(steps)]
+    return [round(x / launches_per_pass, 3) for x in per] if what == "ghz" else [round(x * 1e-3, 4) for x in per]
 
 
 def build_workload(workload, dev, seed=0):
@@ -510,7 +511,15 @@ def main():
     # workgroup and launch, inside the timed region like everything else) into a ring of the last `ring` launches per kernel
     with wkv6_op.ClockProbe(dev, n_slots=64, n_launches=ring) as probe:
         prewarm = prewarm_until_steady(fwd, bwd)
+        # under a profiler (tools/collect_profiles.sh) two empty marker kernels bracket the W warm-up + K timed steps in the dispatch list, so
+        # that tools/aggregate_profiles.py can average the TIMED launches only (the last K of each kernel between the markers); both are
+        # launches, not waits, and both lie outside the timed region
+        marked = under_profiler()
+        if marked:
+            wkv6_op.pass_marker()
         elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
+        if marked:
+            wkv6_op.pass_marker()
         clocks = probe.read()
     fwd_steps = [e[0].elapsed_time(e[1]) for e in ev]
     bwd_steps = [e[1].elapsed_time(e[2]) for e in ev]
@@ -521,6 +530,8 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         fwd_ghz = timed_launch_clocks(clocks, "fwd", args.steps, launches_per_pass)
         bwd_ghz = timed_launch_clocks(clocks, "bwd", args.steps, launches_per_pass)
+        fwd_kus = timed_launch_clocks(clocks, "fwd", args.steps, launches_per_pass, "us")
+        bwd_kus = timed_launch_clocks(clocks, "bwd", args.steps, launches_per_pass, "us")
         seq_tokens = T // launches_per_pass                   # tokens one workgroup walks per launch
 
         def mean_or_none(xs):
@@ -560,7 +571,13 @@ def main():
                        "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
                        # every timed step by itself (HIP events on the launch stream): a steady state shows as flat lists
                        "fwd_ms_steps": [round(x, 4) for x in fwd_steps], "bwd_ms_steps": [round(x, 4) for x in bwd_steps],
-                       "first_last_step_ratio": round((fwd_steps[-1] + bwd_steps[-1]) / (fwd_steps[0] + bwd_steps[0]), 4),
+                       # ... and the kernels alone, from the same launches' in-kernel s_memrealtime stamps (last wave's end - first wave's start): the
+                       # first timed step's EVENT interval also holds the launch latency behind the fence's synchronize (~25 us once per run)
+                       "fwd_kernel_ms_steps": fwd_kus or None, "bwd_kernel_ms_steps": bwd_kus or None,
+                       "first_last_step_ratio": round((fwd_kus[-1] + bwd_kus[-1]) / (fwd_kus[0] + bwd_kus[0]), 4) if fwd_kus and bwd_kus
+                       else round((fwd_steps[-1] + bwd_steps[-1]) / (fwd_steps[0] + bwd_steps[0]), 4),
+                       "step_spread": round((max(a + b for a, b in zip(fwd_steps, bwd_steps)) - min(a + b for a, b in zip(fwd_steps, bwd_steps)))
+                                            / (fwd_ms + bwd_ms), 4),
                        # in-kernel shader clock of the timed launches of each kernel: d(s_memtime) / d(s_memrealtime) x 100 MHz, median
                        # over workgroups (MI355X_MICROARCH.md, DVFS give-back item 6): mean over the timed steps, first and last step
                        "fwd_clock_ghz": mean_or_none(fwd_ghz), "bwd_clock_ghz": mean_or_none(bwd_ghz),

@@ -591,12 +591,22 @@ int wkv6_backward_pair_ex(int B, int T, int C, int H, const void* u, const wkv6_
     return to_rc(launch_chunk_bwd_pair(a[0], a[1], (hipStream_t)stream));
 }
 
+// The chunked halves of wkv6_bi address their fp32 side buffers with 32-bit byte offsets (buffer resources): (T + 128) C fp32 elements must
+// stay below 2^32 bytes (where two workgroups serve a pair the side buffers are [B,T,C] arrays; the one-launch path's are [T][64]).
+// Longer rows take the exact scan kernels, whose indices are 64-bit -- decided before the call enqueues anything.
+static unsigned bi_route(unsigned flags, int T, int C)
+{
+    if (!(flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) && ((long)T + 128) * C >= (1L << 30)) flags |= WKV6_ALGO_SCAN;
+    return flags;
+}
+
 int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* lens, const void* r,
                       const void* k, const void* v, const void* w, const void* u, void* y,
                       void* workspace, size_t workspace_bytes, unsigned flags, void* stream)
 {
     if (int rc = check_shape(B, T, C, H)) return rc;
     if (!r || !k || !v || !w || !u || !y || (!mask && !lens)) return WKV6_ENULL;
+    flags = bi_route(flags, T, C);             // (before anything is enqueued)
     hipStream_t st = (hipStream_t)stream;
     StreamScratch scratch;                     // released (stream-ordered) when this call returns
     BiWorkspace ws;
@@ -606,9 +616,6 @@ int wkv6bi_forward_ex(int B, int T, int C, int H, const int* mask, const int* le
         lens = ws.lens;
     }
     const bool chunked = !(flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN));
-    // the chunked halves address their fp32 side buffers with 32-bit byte offsets (buffer resources): (T + 128) C fp32 elements must
-    // stay below 2^32 bytes (where two workgroups serve a pair the side buffers are [B,T,C] arrays; the one-launch path's are [T][64])
-    if (chunked && ((long)T + 128) * C >= (1L << 30)) return WKV6_EUNSUPPORTED;
     const bool keep = (flags & WKV6_BI_KEEP_CKPT) && chunked;
     ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
     if (chunked && B > 1 && B <= 4096) {
@@ -638,6 +645,7 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
 {
     if (int rc = check_shape(B, T, C, H)) return rc;
     if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw || (!mask && !lens)) return WKV6_ENULL;
+    flags = bi_route(flags, T, C);             // (before anything is enqueued)
     hipStream_t st = (hipStream_t)stream;
     StreamScratch scratch;                     // released (stream-ordered) when this call returns
     BiWorkspace ws;
@@ -646,7 +654,6 @@ int wkv6bi_backward_ex(int B, int T, int C, int H, const int* mask, const int* l
         hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B), dim3(256), 0, st, mask, ws.lens, T);
         lens = ws.lens;
     }
-    if (!(flags & (WKV6_IO_F32 | WKV6_ALGO_SCAN)) && ((long)T + 128) * C >= (1L << 30)) return WKV6_EUNSUPPORTED;   // (as in the forward)
     ScanArgs a = base_args(B, T, C, H, r, k, v, w, u, flags);
     a.gy = gy; a.gr = gr; a.gk = gk; a.gv = gv; a.gw = gw; a.gu = gu;
     a.lens = lens;

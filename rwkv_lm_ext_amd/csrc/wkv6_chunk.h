@@ -89,6 +89,28 @@ __device__ __forceinline__ void halves32(float x, float& lower, float& upper)   
     upper = __uint_as_float(r[1]);
 }
 
+// The persistent wkv6_bi kernels (chunk_fwd_bi_kernel, chunk_bwd12k_bi_kernel) run two kernel bodies per row in a loop.  Read directly,
+// hipcc hoists the bodies' ~45 kernarg loads out of that loop and keeps the whole argument block in scalar registers across both calls,
+// beside each call's ~14 buffer resources: 110-134 scalar spills into vector-register lanes (and, in the backward, vector registers to
+// scratch).  Instead every call re-reads the block from the kernarg segment -- the kernel's first parameter, at offset 0 -- through a pointer
+// the compiler cannot see through, so nothing of it is live from call to call: a call opens with a handful of s_load_dwordx4/8, a few
+// hundred cycles against the microseconds of a call.
+__device__ __forceinline__ void load_kernargs(ScanArgs& dst)
+{
+    typedef const __attribute__((address_space(4))) char kchar;
+    const unsigned long p0 = (unsigned long)(kchar*)__builtin_amdgcn_kernarg_segment_ptr();     // the kernel's first parameter sits at offset 0
+    unsigned lo = (unsigned)p0, hi = (unsigned)(p0 >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    // (an inline-asm result counts as divergent: re-assert uniformity, or the block is fetched with vector loads)
+    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+    typedef const __attribute__((address_space(4))) unsigned kword;
+    kword* const kw = (kword*)(((unsigned long)hi << 32) | lo);
+    // (dword by dword: a memcpy is expanded after the uniformity annotation and comes out as vector loads)
+    static_assert(sizeof(ScanArgs) % 4 == 0, "whole dwords");
+    unsigned* const d = reinterpret_cast<unsigned*>(&dst);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(ScanArgs) / 4); ++i) d[i] = kw[i];
+}
 // In-run clock probe (wkv6_set_clock_buffer): hardware wave 0 of a workgroup stamps {s_memtime, s_memrealtime} at its start (which = 0)
 // and its end (which = 1) straight into the buffer -- nothing stays in registers in between.  a.clk == null: one scalar branch.
 __device__ __forceinline__ void clock_stamp(const ScanArgs& a, unsigned slot, int which)

@@ -754,9 +754,13 @@ __global__ __launch_bounds__(512) void chunk_fwd_pair_kernel(const ScanArgs a0, 
 // ([T][64], 128 KB at T = 512), the reversed-direction scan adds it and rounds once.
 // (one argument block: the reversed-direction problem differs from the forward-direction one in five fields)
 template <bool W_RAW>
-__global__ __launch_bounds__(512) void chunk_fwd_bi_kernel(const ScanArgs a1, float* const ckpt2)
+__global__ __launch_bounds__(512) void chunk_fwd_bi_kernel(const ScanArgs a1_, float* const ckpt2)
 {
-    const unsigned n = (unsigned)(a1.B * a1.H);
+    // (a1_ is read here for the row walk only; the bodies get per-call copies of the argument block: load_kernargs, wkv6_chunk.h)
+    const unsigned n = (unsigned)(a1_.B * a1_.H);
+    const int H_ = a1_.H, T_ = a1_.T, use_u_ = a1_.use_u;
+    const int* const order_ = a1_.order;
+    const int* const lens_ = a1_.lens;
     // the rows are ordered by decreasing length (a.order): slot j takes row j of the first round of gridDim.x rows, row gridDim.x - 1 - j
     // of the second, ... (boustrophedon), so that every slot gets long and short rows alike -- in plain round-robin order slot 0 would
     // take the longest row of every round and the last slot the shortest (+-12 % of the mean at BASELINE configs[2])
@@ -771,8 +775,8 @@ __global__ __launch_bounds__(512) void chunk_fwd_bi_kernel(const ScanArgs a1, fl
     const auto lookup = [&](unsigned row, int& b, int& ntok) {
         b = 0; ntok = 0;
         if (row < n) {
-            b = a1.order ? a1.order[row / a1.H] : (int)(row / a1.H);
-            ntok = a1.lens ? min(max(a1.lens[b], 0), a1.T) : a1.T;
+            b = order_ ? order_[row / H_] : (int)(row / H_);
+            ntok = lens_ ? min(max(lens_[b], 0), T_) : T_;
         }
     };
     int b_cur, ntok_cur;
@@ -786,16 +790,23 @@ __global__ __launch_bounds__(512) void chunk_fwd_bi_kernel(const ScanArgs a1, fl
         int b_nx, ntok_nx;
         lookup(row_nx, b_nx, ntok_nx);
         const int ngrp_cur = (ntok_cur + GRP - 1) / GRP;
-        chunk_fwd_body<W_RAW, false, false, false, true, false, true>(a1, row, blockIdx.x, raw,
-                                                                      FwdChain{b_cur, ntok_cur, pb, chained, true, row, b_cur, ntok_cur, true, false});
+        {
+            ScanArgs a1;
+            load_kernargs(a1);
+            chunk_fwd_body<W_RAW, false, false, false, true, false, true>(a1, row, blockIdx.x, raw,
+                                                                          FwdChain{b_cur, ntok_cur, pb, chained, true, row, b_cur, ntok_cur, true, false});
+        }
         pb = (pb + ngrp_cur) & 1;
         if (!producer_wave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         if (!producer_wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        ScanArgs a2 = a1;
-        a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.ckpt = ckpt2;
-        chunk_fwd_body<W_RAW, false, true, false, true, false, true>(a2, row, blockIdx.x, raw,
-                                                                     FwdChain{b_cur, ntok_cur, pb, true, row_nx < n, row_nx, b_nx, ntok_nx, false, a1.use_u != 0});
+        {
+            ScanArgs a2;
+            load_kernargs(a2);
+            a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.ckpt = ckpt2;
+            chunk_fwd_body<W_RAW, false, true, false, true, false, true>(a2, row, blockIdx.x, raw,
+                                                                         FwdChain{b_cur, ntok_cur, pb, true, row_nx < n, row_nx, b_nx, ntok_nx, false, use_u_ != 0});
+        }
         pb = (pb + ngrp_cur) & 1;
         chained = true;
         __syncthreads();

@@ -130,7 +130,11 @@ template <bool W_RAW, int GEN, bool SPLIT, bool AFF, bool CLK = false, bool CHAI
 __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot, const unsigned sslot = 0, const BwdChain& ch = BwdChain{})
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][RBLK_BYTES] | [3][SBLK][KBLK_BYTES] | tiles | G operand
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    // (persistent wkv6_bi launch: everything derived from the lane index is re-derived per call.  Left visible, hipcc hoists those ~25
+    // lane-invariant address parts of BOTH bodies out of the row loop and keeps them alive across the calls -- vector-register spills)
+    if constexpr (CHAIN) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63;
     const SplitConst spc = split_const();
     const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = SPLIT ? (int)(slot & 1) : 0, bh = SPLIT ? (int)(slot >> 1) : (int)slot;
@@ -621,9 +625,15 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         // loads follow -- vmcnt(3 .. 0) would then wait, every stage, for the stores of the stage before to be acknowledged.  Three
         // stores that the bounds check drops give the first entry the same queue.
         {   // (first half of wkv6_bi: four fp32 side stores -- gk, gw of both blocks -- follow a stage's checkpoint request)
-            const rsrc_t rs_none = make_rsrc(static_cast<bf16_t*>(nullptr), 0u);
+            // (persistent wkv6_bi launch: made per call -- as a constant it is hoisted out of the row loop into four scalar registers the loop
+            // does not have, and ends up in scratch)
+            unsigned none_bytes = 0u;
+            if constexpr (CHAIN) { asm volatile("" : "+s"(none_bytes)); none_bytes = __builtin_amdgcn_readfirstlane(none_bytes); }
+            const rsrc_t rs_none = make_rsrc(static_cast<bf16_t*>(nullptr), none_bytes);
 #pragma unroll
-            for (int i = 0; i < (GEN == 1 ? 4 : 3); ++i) buf_store16(rs_none, 16u * i, make_uint4(0u, 0u, 0u, 0u));   // (distinct: identical ones are merged)
+            // (the data are whatever four live registers hold -- the bonus vector: a zero quad is hoisted out of the persistent launch's row loop and spilled)
+            for (int i = 0; i < (GEN == 1 ? 4 : 3); ++i)
+                buf_store16(rs_none, 16u * i, make_uint4(__float_as_uint(ue[0]), __float_as_uint(ue[1]), __float_as_uint(ue[2]), __float_as_uint(ue[3])));   // (distinct: identical ones are merged)
         }
 
         __syncthreads();                                          // first stage image is ready
@@ -1251,10 +1261,19 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_pair_kernel(const ScanArgs a
 // Infinity Cache instead of making a round trip through HBM (two launches: 16 + 16 B per token-channel).
 // (ONE argument block: the reversed-direction problem is the forward-direction one with `reverse`, no bonus, accumulation, no tail
 // zeroing, no gu and its own checkpoints -- two blocks kept both in scalar registers across the row loop and spilled 200 of them.)
+// (Argument plumbing, round 6.  The two bodies read ~45 fields of the argument block; hipcc hoists those kernarg loads out of the row loop
+// and keeps them in scalar registers across both calls -- beside each call's ~14 buffer resources: 134 scalar spills into vector-register
+// lanes and, with no vector registers left either, 26 of those to scratch (406 v_readlane / v_writelane, 63 scratch instructions around
+// every call; fp32-ew worse: reloads inside the stage loops).  Here every call re-reads the block it needs from the kernarg segment
+// through a pointer the compiler cannot see through (laundered per call), so nothing of it is live from call to call: each call opens
+// with a handful of s_load_dwordx8/16 -- a few hundred cycles against the ~8 us of a call.)
 template <bool W_RAW>
-__global__ __launch_bounds__(768) void chunk_bwd12k_bi_kernel(const ScanArgs a1, float* const ckpt2)
+__global__ __launch_bounds__(768) void chunk_bwd12k_bi_kernel(const ScanArgs a1_, float* const ckpt2)
 {
-    const unsigned n = (unsigned)(a1.B * a1.H);
+    const unsigned n = (unsigned)(a1_.B * a1_.H);
+    const int H_ = a1_.H, T_ = a1_.T;
+    const int* const order_ = a1_.order;
+    const int* const lens_ = a1_.lens;
     // the rows are ordered by decreasing length (a.order): slot j takes row j of the first round of gridDim.x rows, row gridDim.x - 1 - j
     // of the second, ... (boustrophedon), so that every slot gets long and short rows alike -- in plain round-robin order slot 0 would
     // take the longest row of every round and the last slot the shortest (+-12 % of the mean at BASELINE configs[2])
@@ -1262,8 +1281,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_bi_kernel(const ScanArgs a1,
     const auto lookup = [&](unsigned row, int& b, int& ntok) {      // (one row ahead: see BwdChain)
         b = 0; ntok = 0;
         if (row < n) {
-            b = a1.order ? a1.order[row / a1.H] : (int)(row / a1.H);
-            ntok = a1.lens ? min(max(a1.lens[b], 0), a1.T) : a1.T;
+            b = order_ ? order_[row / H_] : (int)(row / H_);
+            ntok = lens_ ? min(max(lens_[b], 0), T_) : T_;
         }
     };
     int b_cur, ntok_cur;
@@ -1273,13 +1292,20 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_bi_kernel(const ScanArgs a1,
         if (row >= n) continue;                                     // (the last round may be short; workgroup-uniform)
         int b_nx, ntok_nx;
         lookup(row_of(it + 1), b_nx, ntok_nx);
-        chunk_bwd12k_body<W_RAW, 1, false, true, false, true>(a1, row, blockIdx.x, BwdChain{b_cur, ntok_cur});
+        {
+            ScanArgs a1;
+            load_kernargs(a1);
+            chunk_bwd12k_body<W_RAW, 1, false, true, false, true>(a1, row, blockIdx.x, BwdChain{b_cur, ntok_cur});
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's partial stores are out ...
         __syncthreads();                                            // ... and every wave's (the LDS tags are re-armed behind this barrier)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        ScanArgs a2 = a1;
-        a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.gu = nullptr; a2.ckpt = ckpt2;
-        chunk_bwd12k_body<W_RAW, 2, false, true, false, true>(a2, row, blockIdx.x, BwdChain{b_cur, ntok_cur});
+        {
+            ScanArgs a2;
+            load_kernargs(a2);
+            a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.gu = nullptr; a2.ckpt = ckpt2;
+            chunk_bwd12k_body<W_RAW, 2, false, true, false, true>(a2, row, blockIdx.x, BwdChain{b_cur, ntok_cur});
+        }
         __syncthreads();
         b_cur = b_nx; ntok_cur = ntok_nx;
     }
@@ -1377,9 +1403,6 @@ hipError_t launch_chunk_bwd_bi(const ScanArgs& a1_, const ScanArgs& a2_, int* sl
     const int n = bi_slots(a1_.B * a1_.H);
     if (slots) *slots = n;
     if (!n || !a1_.ckpt || !a2_.ckpt || a1_.g_in || a1_.rc_in) return hipErrorNotSupported;
-    // (raw bf16 decay only -- the autograd layer's path.  The fp32-ew instantiation of the two-body kernel reloads two spilled registers
-    // inside its stage loops; the reference-signature symbols, which pass fp32 ew, keep the two launches.)
-    if (a1_.wkind != 1) return hipErrorNotSupported;
     if (a1_.wkind != 1 && ((long)a1_.T + 64) * a1_.C >= (1L << 30)) return hipErrorInvalidValue;
     ScanArgs a1 = a1_, a2 = a2_;
     for (ScanArgs* a : {&a1, &a2}) {
@@ -1394,10 +1417,16 @@ hipError_t launch_chunk_bwd_bi(const ScanArgs& a1_, const ScanArgs& a2_, int* sl
         a->aux = reinterpret_cast<float*>(g_stamp_buffer);
 #endif
     }
+    // (both decay kinds since round 6: the reference-signature symbols pass fp32 ew = -exp(w), cuda/wkv6_bi_op.cpp:5-13)
     constexpr size_t lds = BWD12K_LDS;
-    static LdsAttrOnce attr_raw;
-    if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_bwd12k_bi_kernel<true>), lds)) return e;
-    hipLaunchKernelGGL((chunk_bwd12k_bi_kernel<true>), dim3(n), dim3(768), lds, st, a1, a2.ckpt);
+    static LdsAttrOnce attr_raw, attr_ew;
+    if (a1.wkind == 1) {
+        if (hipError_t e = attr_raw.ensure(reinterpret_cast<const void*>(chunk_bwd12k_bi_kernel<true>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_bi_kernel<true>), dim3(n), dim3(768), lds, st, a1, a2.ckpt);
+    } else {
+        if (hipError_t e = attr_ew.ensure(reinterpret_cast<const void*>(chunk_bwd12k_bi_kernel<false>), lds)) return e;
+        hipLaunchKernelGGL((chunk_bwd12k_bi_kernel<false>), dim3(n), dim3(768), lds, st, a1, a2.ckpt);
+    }
     return hipGetLastError();
 }
 

@@ -237,3 +237,30 @@ def test_ragged_rows_share_one_unsplit_launch(ops, two_level):
             c, s_ = host(c), host(s_)
             scale = max(float(np.abs(s_).max()), 1e-3)
             assert float(np.abs(c - s_).max()) <= (4.0 if n in ("gw", "gu") else 2.0) * 2.0 ** -8 * scale, (mask, n)
+
+
+def test_ragged_rows_with_the_reference_decay_kind_share_one_fused_launch(ops, two_level):
+    """The same rows through the reference's decay kind (fp32 ew = -exp(w), what cuda/wkv6_bi_op.cpp:5-13 / cuda/wkv6_bi.py:31-56 pass):
+    since round 6 the fp32-ew instantiations of BOTH persistent wkv6_bi launches (chunk_fwd_bi_kernel<false>,
+    chunk_bwd12k_bi_kernel<false>) serve it -- one launch per pass -- where round 5's backward fell back to two launches.  Rows of
+    0, 1, 31 .. 65 tokens beside long ones against the exact scan kernels on the same ew, with kept checkpoints and self-contained."""
+    B, T, H = 10, 200, 2
+    lens = torch.tensor([0, 1, 31, 32, 33, 63, 64, 65, 200, 129], dtype=torch.int32, device="cuda")
+    d = [dev(t, BF) for t in rand_inputs(9292, B, T, H, "init")]
+    d[3] = (-torch.exp(d[3].float())).contiguous()                       # ew, as WKV_6_BI.forward forms it (cuda/wkv6_bi.py:31)
+    ws = ops.bi_new_workspace(B, T, H * 64, H, "cuda")
+    y = ops.bi_forward_ex(None, *d[:5], H, ws=ws, lens=lens, w_is_ew=True)
+    ys = ops.bi_forward_ex(None, *d[:5], H, algo="scan", lens=lens, w_is_ew=True)
+    scale = float(np.abs(host(ys)).max())
+    assert float(np.abs(host(y) - host(ys)).max()) <= 2.0 * 2.0 ** -8 * scale
+    for b in range(B):
+        assert np.all(host(y)[b, int(lens[b]):] == 0)
+    ref = ops.bi_backward_ex(None, *d, H, algo="scan", lens=lens, w_is_ew=True)
+    for got in (ops.bi_backward_ex(None, *d, H, ws=ws, lens=lens, w_is_ew=True), ops.bi_backward_ex(None, *d, H, lens=lens, w_is_ew=True)):
+        for n, c, s_ in zip(("gr", "gk", "gv", "gw", "gu"), got, ref):
+            c, s_ = host(c), host(s_)
+            scale = max(float(np.abs(s_).max()), 1e-2 if n == "gw" else 1e-3)
+            assert float(np.abs(c - s_).max()) <= (4.0 if n in ("gw", "gu") else 2.0) * 2.0 ** -8 * scale, n
+            if n != "gu":
+                for b in range(B):
+                    assert np.all(c[b, int(lens[b]):] == 0), (n, b)

@@ -18,12 +18,52 @@ def newest(pattern):
     return sorted(by_dir.values())
 
 
+def timed_rows(trace_csv, steps):
+    """Per-kernel statistics over the TIMED launches of a bench.py run under rocprofv3 --kernel-trace: bench.py brackets its W warm-up + K
+    timed steps with two wkv6::pass_marker_kernel launches when it runs under a profiler; the timed launches of a kernel are the last
+    `steps` x (launches per pass) of its dispatches between the markers.  Rows in rocprofv3's own --stats format."""
+    with open(trace_csv) as fh:
+        rows = [r for r in csv.DictReader(fh)]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    marks = [int(r["Dispatch_Id"]) for r in rows if "pass_marker_kernel" in r["Kernel_Name"]]
+    if len(marks) < 2:
+        return None
+    lo, hi = marks[-2], marks[-1]
+    by_kernel = defaultdict(list)
+    for r in rows:
+        d = int(r["Dispatch_Id"])
+        if lo < d < hi and "wkv6::" in r["Kernel_Name"]:
+            by_kernel[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out, total = [], 0
+    for k, durs in by_kernel.items():
+        per_step = max(1, round(len(durs) / (steps["steps"] + steps["warmup"])))
+        durs = durs[-steps["steps"] * per_step:]
+        total += sum(durs)
+        mean = sum(durs) / len(durs)
+        sd = (sum((x - mean) ** 2 for x in durs) / max(1, len(durs) - 1)) ** 0.5
+        out.append([k, len(durs), sum(durs), mean, 0.0, min(durs), max(durs), sd])
+    for r in out:
+        r[4] = 100.0 * r[2] / total
+    return sorted(out, key=lambda r: -r[2])
+
+
+STEPS = {"steps": int(os.environ.get("PROFILE_STEPS", "50")), "warmup": int(os.environ.get("PROFILE_WARMUP", "10"))}   # collect_profiles.sh's command line
 stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
 if stats:      # keep this library's kernels only (the torch kernels of the input generation have kilobyte-long names)
+    # Two scopes in one table.  "timed": the K timed steps only (between bench.py's pass markers) -- what bench.py's HIP events and the
+    # driver measure.  "all": rocprofv3's own --stats rows over the whole process -- pre-warm launches at ramping clocks and the
+    # library's self-test launches (13 us) included; kept for the cross-check, NOT comparable with the bench line.
+    trace = newest(os.path.join(src, "stats", "**", "*kernel_trace.csv"))
+    timed = timed_rows(trace[0], STEPS) if trace else None
     with open(stats[0]) as fh, open(prefix + "_kernel_stats.csv", "w") as out_fh:
-        for i, line in enumerate(fh):
-            if i == 0 or "wkv6" in line or "mask_to_lens" in line:
-                out_fh.write(line)
+        w = csv.writer(out_fh, quoting=csv.QUOTE_NONNUMERIC)
+        for i, row in enumerate(csv.reader(fh)):
+            if i == 0:
+                w.writerow(["Scope"] + row)
+                for r in timed or []:
+                    w.writerow([f"timed ({STEPS['steps']} steps between the pass markers)", r[0], r[1], r[2], round(r[3], 1), round(r[4], 2), r[5], r[6], round(r[7], 1)])
+            elif "wkv6" in row[0] or "mask_to_lens" in row[0]:
+                w.writerow(["all launches of the process (rocprofv3 --stats)"] + row)
 acc = defaultdict(lambda: defaultdict(list))
 for f in newest(os.path.join(src, "pmc*", "**", "*counter_collection.csv")):
     with open(f) as fh:

@@ -5,6 +5,8 @@
 #   bash tools/build_exp_variant.sh noloads      # backward: ... and the r, k, v, w, gy loads too (zero-sized resources return 0): only checkpoints move
 #   bash tools/build_exp_variant.sh fwd_nostore  # forward: y and checkpoint stores dropped
 #   bash tools/build_exp_variant.sh fwd_noloads  # forward: ... and the r, k, v, w loads too: no memory traffic at all
+#   bash tools/build_exp_variant.sh full         # both: the producers' past-the-end selects compiled out (right only where every stage / group is full:
+#                                                #   T a multiple of 64 and no per-row lengths -- config 2): what a tail-free instantiation would buy
 set -e
 name=$1; flags=$2
 src=build_ab/${name}_src; rm -rf $src; mkdir -p $src/rwkv_lm_ext_amd; cp -r rwkv_lm_ext_amd/csrc $src/rwkv_lm_ext_amd/; cp -r include $src/
@@ -41,6 +43,19 @@ if name == "fwd_noloads":
     assert "ntok > 0 ? span * 2 + 128 : 0" in s and "ntok > 0 ? span * 4 + 256 : 0" in s
     s = s.replace("ntok > 0 ? span * 2 + 128 : 0", "0").replace("ntok > 0 ? span * 4 + 256 : 0", "0")
 open(p, "w").write(s)
+PY
+  ;;
+  full) python3 - "$src/rwkv_lm_ext_amd/csrc" <<'PY'
+import sys
+d = sys.argv[1]
+p = d + "/wkv6_chunk_bwd12k.hip"; s = open(p).read()
+old = "const bool valid = sk * STG + pb * BLK + 2 * tq + tt < ntok;"
+assert old in s
+open(p, "w").write(s.replace(old, "const bool valid = true;"))
+p = d + "/wkv6_chunk.hip"; s = open(p).read()
+old = "const bool valid = grp * GRP + wv * BLK + 4 * tq + tt < ntok;"
+assert old in s
+open(p, "w").write(s.replace(old, "const bool valid = true;"))
 PY
   ;;
   *) echo "unknown experiment $name"; exit 1;;

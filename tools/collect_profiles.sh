@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline block refers to.  Run on the GPU box from the repo root:
 #     bash tools/collect_profiles.sh gpurun_out/prof
-# then, back in the container:  python tools/aggregate_profiles.py gpurun_out/prof profiles/r05_final
+# then, back in the container:  python tools/aggregate_profiles.py gpurun_out/prof profiles/r06_final
 # (kernel-trace/stats and every --pmc group are separate runs; no sys/hip trace is combined with --pmc).
 set -e -o pipefail
 OUT=${1:-gpurun_out/prof}
