@@ -123,12 +123,43 @@ __device__ __forceinline__ void split8(const float (&t0)[4], const float (&t1)[4
 // and pair instantiations do not have).
 // What a call of the persistent wkv6_bi launch (CHAIN) knows beyond its argument block: the row's batch index and length, looked up a row ahead
 // by the launch (a.order[row / H] -> a.lens[b]: two dependent memory round trips, ~3000 cycles that used to open every call).
+// Round 6: the calls of a workgroup slot are CHAINED, as the forward's have been since round 5.  A call opens with two serial preparations
+// by its producers (K part of its last stage; then that stage's R part + the K part of the stage in front) and two rounds of v / gy copies
+// by its column waves before its first stage can start: ~4.7 of the ~7 us a call costs on top of its stages, 12 calls per slot at BASELINE
+// configs[2].  The producers are idle while a call's last two stages are consumed (only the R part of stage 0 is left to make): there they
+// now prepare the call that FOLLOWS (the row's reversed half, or the slot's next row) -- its first K part beside this call's last R part
+// during stage 1, its first R part + second K part during stage 0 -- and the column waves move that call's v / gy with their ordinary
+// requests a stage ahead.  The stage -> buffer maps carry a per-call offset (ko, ro) so that the slots simply keep rotating across the
+// call boundary: a call's stage s lives in ring slot (s + ko) mod 3 and R buffer (s + ro) & 1, the next call's first stage takes the slot
+// below stage 0's -- which is the one that is free.  Calls of fewer than two stages are not chained (nor chained into).
 struct BwdChain {
     int b, ntok;
+    int ko, ro;                    // this call's slot offsets
+    bool chained_in;               // the call before this one has made this call's first images and left its next requests in flight
+    bool nx_chain;                 // this call prepares the one behind it: row nx_bh (batch index nx_b, length nx_ntok) of the same argument block,
+    unsigned nx_bh;
+    int nx_b, nx_ntok;
+    bool nx_rev, nx_use_u;         // ... reversed / with the bonus vector
+    const float* nx_ckpt;          // ... and its checkpoints (the row waves request its first one during this call's last stage)
 };
-template <bool W_RAW, int GEN, bool SPLIT, bool AFF, bool CLK = false, bool CHAIN = false>
-__device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot, const unsigned sslot = 0, const BwdChain& ch = BwdChain{})
+// The registers of a call that outlive it in the persistent launch: the producers' inputs in flight and what a stage's K part hands to its
+// R part (see prep), the column waves' v kept for the vg of the stage whose gy arrives an iteration later.
+struct BwdCarry {
+    uint2 pr[2], pk[2], pw[2];
+    float4 pe[2];
+    uint2 ck_[2];
+    float cfr[2][4], clw[2][4], cc8[4];
+    uint2 cvp[2];
+    f4v CK[4];                     // row waves: the checkpoint of the call's first stage pair, requested by the call before it
+};
+// ROLE: 0 = the wave finds its role from its index (every kernel but the persistent wkv6_bi launch); 1 / 2 / 3 = this instantiation holds the
+// row / column / producer role only -- chunk_bwd12k_bi_kernel branches on the role ONCE and runs each role's row loop as its own code, so
+// that what one role carries from call to call (BwdCarry) is not live through the other roles' paths.
+template <bool W_RAW, int GEN, bool SPLIT, bool AFF, bool CLK = false, bool CHAIN = false, int ROLE = 0>
+__device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsigned slot, BwdCarry& cy, const unsigned sslot = 0, const BwdChain& ch = BwdChain{})
 {
+    [[maybe_unused]] const bool chained_in = CHAIN && ch.chained_in, nx_chain = CHAIN && ch.nx_chain;
+    [[maybe_unused]] const int ko = CHAIN ? ch.ko : 0, ro = CHAIN ? ch.ro : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][SBLK][RBLK_BYTES] | [3][SBLK][KBLK_BYTES] | tiles | G operand
     int tid_ = threadIdx.x;
     // (persistent wkv6_bi launch: everything derived from the lane index is re-derived per call.  Left visible, hipcc hoists those ~25
@@ -139,7 +170,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = SPLIT ? (int)(slot & 1) : 0, bh = SPLIT ? (int)(slot >> 1) : (int)slot;
     const int wid = SPLIT ? (hwid < 4 ? hwid + 4 * part : hwid + 4) : hwid;
-    const bool rowrole = wid < 4, producer = wid >= 8;
+    const bool rowrole = ROLE ? ROLE == 1 : wid < 4, producer = ROLE ? ROLE == 3 : wid >= 8;
     const int wv = wid & 3;                                              // tile owned by a row / column wave
     const int pb = wid & 1, half = (wid >> 1) & 1;                       // producer: block of the stage, channel half
     const int b = CHAIN ? ch.b : (a.order ? a.order[bh / a.H] : bh / a.H), h = bh % a.H;
@@ -245,8 +276,12 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     if constexpr (CLK) { if (hwid == 0) clock_stamp(a, slot, 0); }
     const int ngrp = (ntok + STG - 1) / STG;                      // stages
     // images of stage s: R part in buffer s & 1, K part in ring slot s mod 3
-    auto rpart = [&](int stg, int blk) { return smem + (stg & 1) * RBUF_BYTES + blk * RBLK_BYTES; };
-    auto kpart = [&](int stg, int blk) { return smem + KP_OFF + (int)((unsigned)stg % (unsigned)KRING) * KBUF_BYTES + blk * KBLK_BYTES; };
+    // (CHAIN: + the call's slot offsets; stage n' - 1 of the call that follows takes the ring slot below this call's stage 0 and the other
+    // R buffer: rpart_nx / kpart_nx address that call's stage counted from its END, e = n' - 1 - stage)
+    auto rpart = [&](int stg, int blk) { return smem + ((stg + ro) & 1) * RBUF_BYTES + blk * RBLK_BYTES; };
+    auto kpart = [&](int stg, int blk) { return smem + KP_OFF + (int)((unsigned)(stg + ko) % (unsigned)KRING) * KBUF_BYTES + blk * KBLK_BYTES; };
+    [[maybe_unused]] auto rpart_nx = [&](int e, int blk) { return smem + ((ro + 1 + e) & 1) * RBUF_BYTES + blk * RBLK_BYTES; };
+    [[maybe_unused]] auto kpart_nx = [&](int e, int blk) { return smem + KP_OFF + (int)((unsigned)(ko + 2 * KRING - 1 - e) % (unsigned)KRING) * KBUF_BYTES + blk * KBLK_BYTES; };
 
     // ---- producer role: channels ch0..ch0+3, tokens 2tq, 2tq+1 of block pb
     const int c8i = lane & 7, tq = lane >> 3;
@@ -259,31 +294,48 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 
     // register sets: n* = loads in flight (r of stage s-2; k, w of stage s-3), p* = the sets being worked on, c* = what a stage's K part
     // hands to its R part one iteration later (raw k, exponents of fR, the gw multipliers, c_8)
-    uint2 pr[2], pk[2], pw[2];
-    float4 pe[2];
-    uint2 ck_[2];
+    uint2 (&pr)[2] = cy.pr, (&pk)[2] = cy.pk, (&pw)[2] = cy.pw;      // (BwdCarry: in the persistent wkv6_bi launch these outlive the call)
+    float4 (&pe)[2] = cy.pe;
+    uint2 (&ck_)[2] = cy.ck_;
     uint2 pv[2], pg[2], cv_[2];                         // SPLIT: the producers also move v (K part) and gy (R part)
-    float cfr[2][4], clw[2][4], cc8[4] = {0.f, 0.f, 0.f, 0.f};
+    float (&cfr)[2][4] = cy.cfr, (&clw)[2][4] = cy.clw, (&cc8)[4] = cy.cc8;
+    if (!chained_in) { cc8[0] = 0.f; cc8[1] = 0.f; cc8[2] = 0.f; cc8[3] = 0.f; }
     const rsrc_t rs_r = make_rsrc(gr_, nbytes), rs_k = make_rsrc(gk_, nbytes), rs_v = make_rsrc(gv_, nbytes), rs_g = make_rsrc(ggy, nbytes);
     const rsrc_t rs_w = W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base, nbytes)
                               : make_rsrc(reinterpret_cast<const float*>(a.w) + base, ntok > 0 ? (unsigned)(ntok - 1) * a.C * 4u + 256u : 0u);
+    // where a row's inputs live: buffer resources over its first tokens + its token addressing.  `cur` is this call's row; the chained
+    // preparation of the call that follows addresses that call's row (row_in_of)
+    struct RowIn {
+        rsrc_t r, k, v, g, w;
+        TokAddr<AFF> tok;
+    };
+    const RowIn cur{rs_r, rs_k, rs_v, rs_g, rs_w, tok};
+    [[maybe_unused]] auto row_in_of = [&](int b_, int h_, int ntok_, bool rev_) {
+        const long base_ = (long)b_ * a.T * a.C + (long)h_ * HEAD;
+        const unsigned nb_ = ntok_ > 0 ? (unsigned)(ntok_ - 1) * a.C * 2u + 128u : 0u;
+        return RowIn{make_rsrc(reinterpret_cast<const bf16_t*>(a.r) + base_, nb_), make_rsrc(reinterpret_cast<const bf16_t*>(a.k) + base_, nb_),
+                     make_rsrc(reinterpret_cast<const bf16_t*>(a.v) + base_, nb_), make_rsrc(reinterpret_cast<const bf16_t*>(a.gy) + base_, nb_),
+                     W_RAW ? make_rsrc(reinterpret_cast<const bf16_t*>(a.w) + base_, nb_)
+                           : make_rsrc(reinterpret_cast<const float*>(a.w) + base_, ntok_ > 0 ? (unsigned)(ntok_ - 1) * a.C * 4u + 256u : 0u),
+                     TokAddr<AFF>(ntok_, rev_)};
+    };
     const int lp_in[2] = {tok.lane(pb * BLK + 2 * tq, ch0, C_), tok.lane(pb * BLK + 2 * tq + 1, ch0, C_)};
-    auto load_r = [&](int stg) {       // tokens past the end load zeros
+    auto load_r = [&](const RowIn& in, const int (&lp)[2], int stg) {       // tokens past the end load zeros
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            pr[tt] = buf_load8(rs_r, tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_R, lp_in[tt]) * 2u);
-            if constexpr (SPLIT) pg[tt] = buf_load8(rs_g, tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_Y, lp_in[tt]) * 2u);
+            pr[tt] = buf_load8(in.r, in.tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_R, lp[tt]) * 2u);
+            if constexpr (SPLIT) pg[tt] = buf_load8(in.g, in.tok.off(stg * STG, pb * BLK + 2 * tq + tt, ch0, C_, REV_Y, lp[tt]) * 2u);
         }
     };
-    auto load_kw = [&](int stg) {
+    auto load_kw = [&](const RowIn& in, const int (&lp)[2], int stg) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int pl = pb * BLK + 2 * tq + tt;
-            const unsigned ik = tok.off(stg * STG, pl, ch0, C_, REV_K, lp_in[tt]), iw = tok.off(stg * STG, pl, ch0, C_, REV_W, lp_in[tt]);
-            pk[tt] = buf_load8(rs_k, ik * 2u);
-            if constexpr (SPLIT) pv[tt] = buf_load8(rs_v, tok.off(stg * STG, pl, ch0, C_, REV_V, lp_in[tt]) * 2u);
-            if constexpr (W_RAW) pw[tt] = buf_load8(rs_w, iw * 2u);
-            else pe[tt] = buf_load16f(rs_w, iw * 4u);
+            const unsigned ik = in.tok.off(stg * STG, pl, ch0, C_, REV_K, lp[tt]), iw = in.tok.off(stg * STG, pl, ch0, C_, REV_W, lp[tt]);
+            pk[tt] = buf_load8(in.k, ik * 2u);
+            if constexpr (SPLIT) pv[tt] = buf_load8(in.v, in.tok.off(stg * STG, pl, ch0, C_, REV_V, lp[tt]) * 2u);
+            if constexpr (W_RAW) pw[tt] = buf_load8(in.w, iw * 2u);
+            else pe[tt] = buf_load16f(in.w, iw * 4u);
         }
     };
     // (round 5: no second register set.  The requests for the stages behind go out from INSIDE the preparation, right behind the last read of
@@ -300,9 +352,10 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     // (profiles/r04_stamps_bwd12k_v1.txt).
     // (HASR / HASK are compile-time: a run-time `if (sk >= 0)` would cut the body into the very basic blocks it is meant to avoid;
     // the lane-predicated stores -- r.u.k, E8, E16, E16m8 -- come last for the same reason)
-    auto prep = [&](auto HASR, auto HASK, int sr, int sk, int next_r, int next_k) {   // next_*: stages whose r / k, w are requested (any stage < 0: none)
-        char* const rb = rpart(HASR ? sr : 0, pb);
-        char* const kb = kpart(HASK ? sk : 0, pb);
+    // (round 6: the images' addresses, the K stage's row length, the R stage's bonus vector and the row the requests go to are parameters --
+    // the chained preparation of the persistent launch makes the R part of one call beside the K part of the next)
+    auto prep = [&](auto HASR, auto HASK, char* const rb, char* const kb, int sk, int ntok_k, const float (&uu)[4],
+                    const RowIn& rq, const int (&rq_lp)[2], int next_r, int next_k) {   // next_*: stages of row rq whose r / k, w are requested (< 0: none)
         float r[2][4], ko[2][4], k[2][4], cs[2][4], lwn[2][4], coef[2] = {0.f, 0.f};
         // ---- R, first half: everything that reads the carried raw k and gw multipliers (the K part below replaces them)
         if constexpr (HASR) {
@@ -338,12 +391,12 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 }
             }
         }
-        if constexpr (HASR) load_r(next_r);                      // (pr, pg are dead)
+        if constexpr (HASR) load_r(rq, rq_lp, next_r);           // (pr, pg are dead)
         // ---- K, first half: log-decays of the stage's tokens, their sums inside the lane, the gw multipliers
         if constexpr (HASK) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const bool valid = sk * STG + pb * BLK + 2 * tq + tt < ntok;
+                const bool valid = sk * STG + pb * BLK + 2 * tq + tt < ntok_k;
                 k[tt][0] = bf_lo(pk[tt].x); k[tt][1] = bf_hi(pk[tt].x); k[tt][2] = bf_lo(pk[tt].y); k[tt][3] = bf_hi(pk[tt].y);
                 ck_[tt] = pk[tt];
                 if constexpr (SPLIT) {
@@ -373,7 +426,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #pragma unroll
                     for (int c = 0; c < 4; ++c) lwn[tt][c] *= exp2_fast(LOG2E * fminf(lwn[tt][c] - LW_MIN, 0.f));
             }
-            load_kw(next_k);                                      // (pk, pw / pe, pv are dead)
+            load_kw(rq, rq_lp, next_k);                           // (pk, pw / pe, pv are dead)
         } else {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
@@ -538,14 +591,15 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     };
     constexpr std::true_type yes_c{};
     constexpr std::false_type no_c{};
+    [[maybe_unused]] const int nxn = CHAIN ? (ch.nx_ntok + STG - 1) / STG : 0;        // stages of the call that follows
     if (producer) {
         // =============== producers: R part of stage s-1 and K part of stage s-2 while stage s is consumed =====
-        if (ngrp > 0) {
-            load_kw(ngrp - 1);
-            load_r(ngrp - 1);
-            prep(no_c, yes_c, -1, ngrp - 1, -1, ngrp - 2);          // K part of the last stage (requests k, w of the stage in front)
-            if (ngrp > 1) prep(yes_c, yes_c, ngrp - 1, ngrp - 2, ngrp - 2, ngrp - 3);  // its R part, and the K part of the stage in front
-            else prep(yes_c, no_c, 0, -1, -1, -1);
+        if (!chained_in && ngrp > 0) {
+            load_kw(cur, lp_in, ngrp - 1);
+            load_r(cur, lp_in, ngrp - 1);
+            prep(no_c, yes_c, rpart(0, pb), kpart(ngrp - 1, pb), ngrp - 1, ntok, uu, cur, lp_in, -1, ngrp - 2);   // K part of the last stage (requests k, w of the stage in front)
+            if (ngrp > 1) prep(yes_c, yes_c, rpart(ngrp - 1, pb), kpart(ngrp - 2, pb), ngrp - 2, ntok, uu, cur, lp_in, ngrp - 2, ngrp - 3);  // its R part, and the K part of the stage in front
+            else prep(yes_c, no_c, rpart(0, pb), kpart(0, pb), -1, ntok, uu, cur, lp_in, -1, -1);
         }
         __syncthreads();
         // steady state: stages ngrp-1 .. 2 (a full R + K preparation each); the last two stages are peeled so that the loop body
@@ -557,17 +611,39 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 #endif
             WKV6_T(ts1);
             WKV6_T(ts2);
-            prep(yes_c, yes_c, grp - 1, grp - 2, grp - 2, grp - 3);   // r of stage s-1, k / w of stage s-2; requests r of s-2, k / w of s-3
+            prep(yes_c, yes_c, rpart(grp - 1, pb), kpart(grp - 2, pb), grp - 2, ntok, uu, cur, lp_in, grp - 2, grp - 3);   // r of stage s-1, k / w of stage s-2; requests r of s-2, k / w of s-3
             WKV6_T(ts3);
             __syncthreads();
             WKV6_T(ts4);
             WKV6_ACC(0, ts1, ts0); WKV6_ACC(1, ts2, ts1); WKV6_ACC(2, ts3, ts2); WKV6_ACC(3, ts4, ts3);
         }
-        if (ngrp >= 2) {                                           // stage 1 is consumed: only the R part of stage 0 is left to make
-            prep(yes_c, no_c, 0, -1, -1, -1);
-            __syncthreads();
+        bool chained_out = false;
+        if constexpr (CHAIN) {
+            if (nx_chain) {   // (implies ngrp >= 2 and nxn >= 2: chunk_bwd12k_bi_kernel)
+                // the call that follows: its row's inputs, its bonus vector
+                const int nxh = (int)(ch.nx_bh % (unsigned)a.H);
+                const RowIn nx = row_in_of(ch.nx_b, nxh, ch.nx_ntok, ch.nx_rev);
+                const int lp_nx[2] = {nx.tok.lane(pb * BLK + 2 * tq, ch0, C_), nx.tok.lane(pb * BLK + 2 * tq + 1, ch0, C_)};
+                float uu_nx[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ch.nx_use_u) io4<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.u) + nxh * HEAD + ch0, uu_nx);
+                // stage 1 is consumed: the R part of stage 0 beside the K part of that call's LAST stage (into the ring slot below stage 0's)
+                load_kw(nx, lp_nx, nxn - 1);
+                prep(yes_c, yes_c, rpart(0, pb), kpart_nx(0, pb), nxn - 1, ch.nx_ntok, uu, nx, lp_nx, nxn - 1, nxn - 2);
+                __syncthreads();
+                // stage 0 is consumed: that call's first R part (into the R buffer stage 0 does not use) and its second K part; its
+                // requests for the stages behind stay in flight across the call boundary
+                prep(yes_c, yes_c, rpart_nx(0, pb), kpart_nx(1, pb), nxn - 2, ch.nx_ntok, uu_nx, nx, lp_nx, nxn - 2, nxn - 3);
+                __syncthreads();
+                chained_out = true;
+            }
         }
-        if (ngrp >= 1) __syncthreads();                            // stage 0 is consumed
+        if (!chained_out) {
+            if (ngrp >= 2) {                                           // stage 1 is consumed: only the R part of stage 0 is left to make
+                prep(yes_c, no_c, rpart(0, pb), kpart(0, pb), -1, ntok, uu, cur, lp_in, -1, -1);
+                __syncthreads();
+            }
+            if (ngrp >= 1) __syncthreads();                            // stage 0 is consumed
+        }
     } else
     if (rowrole) {
         // =============== key rows [16wv, 16wv+16): gr, gk, gw, gu ==========================================
@@ -591,7 +667,7 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         const int segs = a.ckpt_segs > 1 ? a.ckpt_segs : 1;
         const long ck_slot0 = ((long)((b / segs) * a.H + h) * segs + b % segs) * nslots;
         const rsrc_t rs_ck = make_rsrc(a.ckpt + ck_slot0 * (HEAD * HEAD), nslots * 16384u);
-        f4v CK[4];
+        f4v (&CK)[4] = cy.CK;                                     // (BwdCarry: a chained call finds its first checkpoint requested)
         auto request_ckpt = [&](int stg) {
             const unsigned off = (unsigned)(stg >> 1) * 16384u + (unsigned)wv * 4096u + (unsigned)lane * 16u;
 #pragma unroll
@@ -616,9 +692,12 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             }
         };
         // (as for the column waves' G below: whatever was loaded for the loop is waited for in front of it)
+        // (persistent wkv6_bi launch: a call's opening latencies count -- 12 calls per slot at BASELINE configs[2] --: the checkpoint request goes out
+        // in front of the wait for the bonus vector, not behind it; a chained call's was made by the call before it)
+        if constexpr (CHAIN) { if (!chained_in && ngrp > 0) request_ckpt(ngrp - 1); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(ue[q]), "+v"(Rc[q]));
-        if (ngrp > 0) request_ckpt(ngrp - 1);
+        if constexpr (!CHAIN) { if (ngrp > 0) request_ckpt(ngrp - 1); }
         // The vector-memory counter counts loads and stores alike, in order.  Inside the loop the checkpoint request of a stage is
         // followed by its three gradient stores, so the wait for the first checkpoint register may leave six requests in flight; hipcc
         // sizes the one s_waitcnt at the loop head for the worse of its two entries, and on first entry only the other three checkpoint
@@ -828,6 +907,17 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             // L2 -- 16 KB per pair and workgroup through the CU's vector-memory pipe, which these kernels keep ~80 % busy:
             // profiles/r05_memory_pipe.md; same-box -1 %.)
             if (grp > 0 && !(grp & 1)) request_ckpt(grp - 1);
+            if constexpr (CHAIN) {
+                if (nx_chain && grp == 0) {   // the call that follows: the checkpoint of its last stage pair, a chain's length ahead of its first use
+                    const rsrc_t rs_nx = make_rsrc(ch.nx_ckpt + ((long)ch.nx_b * a.H + (long)(ch.nx_bh % (unsigned)a.H)) * nslots * (HEAD * HEAD), nslots * 16384u);
+                    const unsigned off = (unsigned)((nxn - 1) >> 1) * 16384u + (unsigned)wv * 4096u + (unsigned)lane * 16u;
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        const float4 t = buf_load16f(rs_nx, off + jt * 1024u);
+                        CK[jt] = f4v{t.x, t.y, t.z, t.w};
+                    }
+                }
+            }
             WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
             if constexpr (!SPLIT) {
                 WKV6_EV(2);
@@ -954,31 +1044,32 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
         // global memory into the images, with the two half sums of vg_a = gy_a . v_a (the v of a stage is kept in registers for the one
         // iteration until its gy arrives).  lane = (token tl, channels 4cl .. 4cl+3); requested at the head of a stage, written at its end.
         const int tl = lane >> 4, cl = lane & 15;
-        uint2 cv[SBLK], cg[SBLK], cvp[SBLK];
+        uint2 cv[SBLK], cg[SBLK];
+        uint2 (&cvp)[SBLK] = cy.cvp;                           // (BwdCarry: outlives the call in the persistent wkv6_bi launch)
         const int lp_vg = tok.lane(4 * wv + tl, 4 * cl, C_);
-        auto load_v = [&](int stg) {
+        auto load_v = [&](const RowIn& in, int lp, int stg) {
 #pragma unroll
             for (int blk = 0; blk < SBLK; ++blk) {
-                cv[blk] = buf_load8(rs_v, tok.off(stg * STG + blk * BLK, 4 * wv + tl, 4 * cl, C_, REV_V, lp_vg) * 2u);
+                cv[blk] = buf_load8(in.v, in.tok.off(stg * STG + blk * BLK, 4 * wv + tl, 4 * cl, C_, REV_V, lp) * 2u);
             }
         };
-        auto load_gy = [&](int stg) {
+        auto load_gy = [&](const RowIn& in, int lp, int stg) {
 #pragma unroll
             for (int blk = 0; blk < SBLK; ++blk) {
-                cg[blk] = buf_load8(rs_g, tok.off(stg * STG + blk * BLK, 4 * wv + tl, 4 * cl, C_, REV_Y, lp_vg) * 2u);
+                cg[blk] = buf_load8(in.g, in.tok.off(stg * STG + blk * BLK, 4 * wv + tl, 4 * cl, C_, REV_Y, lp) * 2u);
             }
         };
-        auto copy_v = [&](int stg) {       // cv -> K part of stage stg; kept in cvp for the stage's vg
+        auto copy_v = [&](char* const k0) {       // cv -> the K part whose block 0 is k0; kept in cvp for the stage's vg
 #pragma unroll
             for (int blk = 0; blk < SBLK; ++blk) {
-                *reinterpret_cast<uint2*>(kpart(stg, blk) + K_V * ARR + (4 * wv + tl) * RSB + 8 * cl) = cv[blk];
+                *reinterpret_cast<uint2*>(k0 + blk * KBLK_BYTES + K_V * ARR + (4 * wv + tl) * RSB + 8 * cl) = cv[blk];
                 cvp[blk] = cv[blk];
             }
         };
-        auto copy_gy = [&](int stg) {      // cg -> R part of stage stg, with vg from cvp (= v of the same stage)
+        auto copy_gy = [&](char* const r0) {      // cg -> the R part whose block 0 is r0, with vg from cvp (= v of the same stage)
 #pragma unroll
             for (int blk = 0; blk < SBLK; ++blk) {
-                char* const rb = rpart(stg, blk);
+                char* const rb = r0 + blk * RBLK_BYTES;
                 const int tok = 4 * wv + tl;
                 *reinterpret_cast<uint2*>(rb + R_GY * ARR + tok * RSB + 8 * cl) = cg[blk];
                 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -990,6 +1081,15 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                 if ((cl & 7) == 0) *reinterpret_cast<float*>(rb + ROFF_VG + ((cl >> 3) * 16 + tok) * 4) = vg;
             }
         };
+        // (persistent wkv6_bi launch: the call that follows -- this wave moves its first v / gy rows during this call's last two stages)
+        [[maybe_unused]] RowIn nx = cur;
+        [[maybe_unused]] int lp_vg_nx = lp_vg;
+        if constexpr (CHAIN) {
+            if (nx_chain) {
+                nx = row_in_of(ch.nx_b, (int)(ch.nx_bh % (unsigned)a.H), ch.nx_ntok, ch.nx_rev);
+                lp_vg_nx = nx.tok.lane(4 * wv + tl, 4 * cl, C_);
+            }
+        }
         // (E16m8 of the block whose K part is kb) (.) G, split into the bf16 hi | lo fragments of the two k-steps
         auto scale_split = [&](const char* kb, b8v (&h)[2], b8v (&l)[2]) {
 #pragma unroll
@@ -1012,14 +1112,14 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
             }
         };
         [[maybe_unused]] b8v nh[2] = {}, nl[2] = {};                // block 1's operand of the NEXT stage, across the barrier
-        if (!SPLIT && ngrp > 0) {                                  // (SPLIT: the producers of this workgroup move v and gy)
-            load_v(ngrp - 1);
-            load_gy(ngrp - 1);
-            copy_v(ngrp - 1);
-            copy_gy(ngrp - 1);
+        if (!SPLIT && !chained_in && ngrp > 0) {                   // (SPLIT: the producers of this workgroup move v and gy)
+            load_v(cur, lp_vg, ngrp - 1);
+            load_gy(cur, lp_vg, ngrp - 1);
+            copy_v(kpart(ngrp - 1, 0));
+            copy_gy(rpart(ngrp - 1, 0));
             if (ngrp > 1) {
-                load_v(ngrp - 2);
-                copy_v(ngrp - 2);
+                load_v(cur, lp_vg, ngrp - 2);
+                copy_v(kpart(ngrp - 2, 0));
             }
         }
         __syncthreads();                                          // first stage image is ready
@@ -1056,8 +1156,19 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     }
                     WKV6_EV(0);
                     WKV6_T5(2, tp0);
-                    if (grp > 0) load_gy(grp - 1);                 // this wave's requests for the stages behind
-                    if (grp > 1) load_v(grp - 2);
+                    // this wave's requests for the stages behind (CHAIN: past this call's first stage they go to the call that follows --
+                    // stage 1 requests its last stage's v, stage 0 its last stage's gy and the v of the stage in front)
+                    if constexpr (CHAIN) {
+                        // (unconditional, from a SELECTED row: as branches the two requests make cv / cg merges of "loaded here" and "loaded there",
+                        // which hipcc resolves with an s_waitcnt vmcnt(0) inside the stage loop; past the row's first stage an unchained call's
+                        // requests lie outside its buffer resources and cost nothing)
+                        const bool g_nx = nx_chain && grp == 0, v_nx = nx_chain && grp <= 1;
+                        load_gy(g_nx ? nx : cur, g_nx ? lp_vg_nx : lp_vg, g_nx ? nxn - 1 : grp - 1);
+                        load_v(v_nx ? nx : cur, v_nx ? lp_vg_nx : lp_vg, v_nx ? (grp == 1 ? nxn - 1 : nxn - 2) : grp - 2);
+                    } else {
+                        if (grp > 0) load_gy(cur, lp_vg, grp - 1);
+                        if (grp > 1) load_v(cur, lp_vg, grp - 2);
+                    }
                     WKV6_T5(2, tp1); WKV6_ACC5(2, tp1, tp0);
                 } else {
                     scale_split(kb, gh[blk], gl[blk]);
@@ -1193,8 +1304,12 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
                     publish(TAG_GA, tagv - 1);                     // (ordered before the row waves' reads by the stage barrier as well)
                 }
             }
-            if (!SPLIT && grp > 0) copy_gy(grp - 1);           // (uses cvp = v of stage s-1, before copy_v replaces it)
-            if (!SPLIT && grp > 1) copy_v(grp - 2);
+            if constexpr (!SPLIT) {
+                if (grp > 0) copy_gy(rpart(grp - 1, 0));           // (uses cvp = v of stage s-1, before copy_v replaces it)
+                else if (CHAIN && nx_chain) copy_gy(rpart_nx(0, 0));
+                if (grp > 1) copy_v(kpart(grp - 2, 0));
+                else if (CHAIN && nx_chain) copy_v(grp == 1 ? kpart_nx(0, 0) : kpart_nx(1, 0));
+            }
             WKV6_T(ts2);
             __syncthreads();
             WKV6_T(ts3);
@@ -1242,7 +1357,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
 template <bool W_RAW, int GEN, bool SPLIT, bool AFF>
 __global__ __launch_bounds__(SPLIT ? 512 : 768) void chunk_bwd12k_kernel(const ScanArgs a)
 {
-    chunk_bwd12k_body<W_RAW, GEN, SPLIT, AFF, GEN == 0>(a, blockIdx.x);
+    BwdCarry cy;       // (registers that outlive a call only in the persistent wkv6_bi launch: plain locals here)
+    chunk_bwd12k_body<W_RAW, GEN, SPLIT, AFF, GEN == 0>(a, blockIdx.x, cy);
 }
 
 // the backward of chunk_fwd_pair_kernel (wkv6_chunk.hip): two problems of one shape, slots [0, B H) serve a0, the rest a1
@@ -1251,7 +1367,8 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_pair_kernel(const ScanArgs a
 {
     const unsigned n = (unsigned)(a0.B * a0.H);
     const bool second = blockIdx.x >= n;
-    chunk_bwd12k_body<W_RAW, 0, false, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x);   // (per-tensor reversal maps: general addressing)
+    BwdCarry cy;
+    chunk_bwd12k_body<W_RAW, 0, false, false>(second ? a1 : a0, second ? blockIdx.x - n : blockIdx.x, cy);   // (per-tensor reversal maps: general addressing)
 }
 
 // Both halves of wkv6_bi in one persistent launch (cuda/wkv6_bi_cuda.cu:363-377 runs one forward and three backward launches): workgroup
@@ -1285,30 +1402,54 @@ __global__ __launch_bounds__(768) void chunk_bwd12k_bi_kernel(const ScanArgs a1_
             ntok = lens_ ? min(max(lens_[b], 0), T_) : T_;
         }
     };
-    int b_cur, ntok_cur;
-    lookup(row_of(0), b_cur, ntok_cur);
-    for (unsigned it = 0; it * gridDim.x < n; ++it) {
-        const unsigned row = row_of(it);
-        if (row >= n) continue;                                     // (the last round may be short; workgroup-uniform)
-        int b_nx, ntok_nx;
-        lookup(row_of(it + 1), b_nx, ntok_nx);
-        {
-            ScanArgs a1;
-            load_kernargs(a1);
-            chunk_bwd12k_body<W_RAW, 1, false, true, false, true>(a1, row, blockIdx.x, BwdChain{b_cur, ntok_cur});
+    const int use_u_ = a1_.use_u;
+    const float* const ckpt1_ = a1_.ckpt;
+    // one copy of the row loop per role (see ROLE at chunk_bwd12k_body): the three run the same calls in the same order and meet at the same barriers
+    const auto rows = [&](auto role_c) {
+        constexpr int ROLE = decltype(role_c)::value;
+        int b_cur, ntok_cur;
+        lookup(row_of(0), b_cur, ntok_cur);
+        BwdCarry cy;                                                    // the registers that outlive a call (chained calls: BwdChain)
+        int ko = 0, ro = 0;                                             // stage -> buffer offsets of the call that starts: they rotate on across the calls
+        bool chained = false;                                           // ... which the call before it has prepared for
+        const auto mod3 = [](int x) { return ((x % KRING) + KRING) % KRING; };
+        for (unsigned it = 0; it * gridDim.x < n; ++it) {
+            const unsigned row = row_of(it);
+            if (row >= n) continue;                                     // (the last round may be short; workgroup-uniform)
+            const unsigned row_nx = row_of(it + 1);
+            int b_nx, ntok_nx;
+            lookup(row_nx, b_nx, ntok_nx);
+            const int n_cur = (ntok_cur + STG - 1) / STG, n_nx = (ntok_nx + STG - 1) / STG;
+            // a call prepares the one behind it when both have at least two stages (the producers' idle time is a call's last two stages)
+            const bool chain12 = n_cur >= 2, chain2n = row_nx < n && n_cur >= 2 && n_nx >= 2;
+            {
+                ScanArgs a1;
+                load_kernargs(a1);
+                chunk_bwd12k_body<W_RAW, 1, false, true, false, true, ROLE>(a1, row, cy, blockIdx.x,
+                                                                            BwdChain{b_cur, ntok_cur, ko, ro, chained, chain12, row, b_cur, ntok_cur, true, false, ckpt2});
+            }
+            ko = mod3(ko - n_cur); ro = (ro - n_cur) & 1;               // (the call that starts next is this row's reversed half: as many stages)
+            // (the producer waves write no global memory, and a chained call has left their next requests in flight: they take no part in the fences)
+            if constexpr (ROLE != 3) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's partial stores are out ...
+            __syncthreads();                                            // ... and every wave's (the LDS tags are re-armed behind this barrier)
+            if constexpr (ROLE != 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            {
+                ScanArgs a2;
+                load_kernargs(a2);
+                a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.gu = nullptr; a2.ckpt = ckpt2;
+                chunk_bwd12k_body<W_RAW, 2, false, true, false, true, ROLE>(a2, row, cy, blockIdx.x,
+                                                                            BwdChain{b_cur, ntok_cur, ko, ro, chain12, chain2n, row_nx, b_nx, ntok_nx, false, use_u_ != 0, ckpt1_});
+            }
+            ko = mod3(ko - n_nx); ro = (ro - n_nx) & 1;                 // (the call that starts next is the next row's first half)
+            chained = chain2n;
+            __syncthreads();
+            b_cur = b_nx; ntok_cur = ntok_nx;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's partial stores are out ...
-        __syncthreads();                                            // ... and every wave's (the LDS tags are re-armed behind this barrier)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        {
-            ScanArgs a2;
-            load_kernargs(a2);
-            a2.reverse = 1; a2.use_u = 0; a2.accumulate = 1; a2.zero_tail = 0; a2.gu = nullptr; a2.ckpt = ckpt2;
-            chunk_bwd12k_body<W_RAW, 2, false, true, false, true>(a2, row, blockIdx.x, BwdChain{b_cur, ntok_cur});
-        }
-        __syncthreads();
-        b_cur = b_nx; ntok_cur = ntok_nx;
-    }
+    };
+    const int hw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (hw < 4) rows(std::integral_constant<int, 1>{});
+    else if (hw < 8) rows(std::integral_constant<int, 2>{});
+    else rows(std::integral_constant<int, 3>{});
 }
 
 template <bool W_RAW, int GEN, bool AFF> hipError_t launch_bwd12k_inst2(const ScanArgs& a, hipStream_t st)

@@ -49,7 +49,7 @@ PY
 import sys
 d = sys.argv[1]
 p = d + "/wkv6_chunk_bwd12k.hip"; s = open(p).read()
-old = "const bool valid = sk * STG + pb * BLK + 2 * tq + tt < ntok;"
+old = "const bool valid = sk * STG + pb * BLK + 2 * tq + tt < ntok_k;"
 assert old in s
 open(p, "w").write(s.replace(old, "const bool valid = true;"))
 p = d + "/wkv6_chunk.hip"; s = open(p).read()
