@@ -31,7 +31,7 @@ FWD_BYTES, BWD_BYTES = 10, 18   # per token-channel
 GROUP_TOKENS, STAGE_TOKENS = 64, 32     # the forward kernel's loop unit (one workgroup barrier per 64-token group), the backward's (32-token stage)
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_final_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_final_pmc.json")
 
 
 _REAL_STDOUT = None

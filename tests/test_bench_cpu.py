@@ -29,7 +29,7 @@ def test_committed_pmc_figures_are_consistent():
 
 def test_committed_bench_lines_carry_the_contract_fields():
     root = os.path.dirname(os.path.abspath(bench.__file__))
-    for name in ("r05_bench_final.json", "r05_bench_bi.json", "r05_bench_infctx.json", "r04_bench_final.json"):
+    for name in ("r06_bench_final.json", "r06_bench_driver_style.json", "r06_bench_bi.json", "r06_bench_infctx.json", "r05_bench_final.json", "r04_bench_final.json"):
         with open(os.path.join(root, "profiles", name)) as f:
             d = json.loads(f.read())
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -71,3 +71,24 @@ def test_live_counter_rows_reduce_to_per_launch_hbm_bytes():
     n = bench.PMC_CHILD_STEPS
     assert out["_pass_fwd"]["counters"] == {"FETCH_SIZE": 80.0 / n, "WRITE_SIZE": 160.0 / n}
     assert out["_pass_bwd"]["counters"] == {"FETCH_SIZE": (8.0 + 1600.0) / n, "WRITE_SIZE": (16.0 + 800.0) / n}
+
+
+def test_round6_bench_line_proves_its_steady_state():
+    """the committed driver-structured line (python bench.py --steps 20 --warmup 5) carries every timed step, the in-run
+    clocks of the first and last timed launch and the pre-warm record; its first and last timed steps (kernels alone) differ by < 3 %, and
+    its per-kernel means agree with the committed kernel statistics over the timed launches (profiles/r06_final_kernel_stats.csv) within 3 %."""
+    import csv
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    d = json.loads(open(os.path.join(root, "profiles", "r06_bench_driver_style.json")).read())
+    c = d["config"]
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["prewarm_converged"] and 300 <= d["prewarm_ms"] <= 2100
+    assert len(c["fwd_ms_steps"]) == 20 and len(c["bwd_ms_steps"]) == 20 and len(c["fwd_kernel_ms_steps"]) == 20
+    assert abs(c["first_last_step_ratio"] - 1.0) < 0.03
+    assert abs(sum(c["fwd_ms_steps"]) / 20 - c["fwd_ms"]) < 1e-3 and abs(sum(c["bwd_ms_steps"]) / 20 - c["bwd_ms"]) < 1e-3
+    assert len(c["fwd_clock_ghz_first_last"]) == 2 and len(c["bwd_clock_ghz_first_last"]) == 2
+    assert abs(c["cycles_per_group"] - c["fwd_ms"] * 1e-3 * c["fwd_clock_ghz"] * 1e9 / 64) < 2.0
+    assert abs(c["cycles_per_stage"] - c["bwd_ms"] * 1e-3 * c["bwd_clock_ghz"] * 1e9 / 128) < 2.0
+    with open(os.path.join(root, "profiles", "r06_final_kernel_stats.csv")) as fh:
+        timed = {("fwd" if "chunk_fwd_kernel" in r["Name"] else "bwd"): float(r["AverageNs"]) * 1e-6
+                 for r in csv.DictReader(fh) if r["Scope"].startswith("timed") and ("chunk_fwd_kernel" in r["Name"] or "chunk_bwd12k_kernel" in r["Name"])}
+    assert abs(timed["fwd"] / c["fwd_ms"] - 1.0) < 0.03 and abs(timed["bwd"] / c["bwd_ms"] - 1.0) < 0.03, (timed, c["fwd_ms"], c["bwd_ms"])
