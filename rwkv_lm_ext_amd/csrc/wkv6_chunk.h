@@ -111,6 +111,22 @@ __device__ __forceinline__ void load_kernargs(ScanArgs& dst)
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(ScanArgs) / 4); ++i) d[i] = kw[i];
 }
+// Workgroup slot -> (batch, head) row of the plain kernels.  Workgroups are dealt round-robin over the 8 XCDs (slots s and s + 8 share one:
+// MI355X_MICROARCH.md), so in slot order an XCD's L2 sees heads h, h + 8, h + 16, h + 24 of a token row: 128-byte pieces at a 1 KB stride.
+// WKV6_XCD_REMAP = 1 gives every XCD a contiguous range of (batch, head) rows instead -- at B = 8, H = 32 all 32 heads of one batch row,
+// i.e. whole 4 KB token rows per L2 (profiles/r06_xcd_remap.txt has the A/B).  A permutation of the rows: results cannot change.
+#ifndef WKV6_XCD_REMAP
+#define WKV6_XCD_REMAP 0
+#endif
+__device__ __forceinline__ unsigned xcd_row_of_slot(unsigned slot, unsigned n)
+{
+#if WKV6_XCD_REMAP == 1
+    return (n & 7u) ? slot : (slot & 7u) * (n >> 3) + (slot >> 3);
+#else
+    return slot;
+#endif
+}
+
 // In-run clock probe (wkv6_set_clock_buffer): hardware wave 0 of a workgroup stamps {s_memtime, s_memrealtime} at its start (which = 0)
 // and its end (which = 1) straight into the buffer -- nothing stays in registers in between.  a.clk == null: one scalar branch.
 __device__ __forceinline__ void clock_stamp(const ScanArgs& a, unsigned slot, int which)

@@ -129,7 +129,8 @@ __device__ __forceinline__ void chunk_fwd_body(const ScanArgs& a, const unsigned
     // of the four consumers (value columns [32 part, 32 part + 32)): hardware wave w plays consumer 2 part + w for w < 2 and
     // producer w - 2 (wave id 4 + w - 2) otherwise.  The preparation is duplicated, on CUs that would otherwise idle.
     const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform, provably so
-    const int part = a.split ? (int)(slot & 1) : 0, bh = a.split ? (int)(slot >> 1) : (int)slot;
+    const int part = a.split ? (int)(slot & 1) : 0;
+    const int bh = a.split ? (int)(slot >> 1) : (CLK ? (int)xcd_row_of_slot(slot, (unsigned)(a.B * a.H)) : (int)slot);   // (CLK: the plain kernel)
     // Role -> hardware wave.  The waves of a workgroup go to the CU's four SIMDs round-robin (hardware waves w and w + 4 share one:
     // profiles/r06_fwd_pairing.txt has the HW_ID read-back).  WKV6_FWD_PAIR = 0: waves 0..3 consume, 4..7 produce -- one producer and one
     // consumer per SIMD.  1: the roles are paired with themselves -- two SIMDs host two producers each, two host two consumers each (split

@@ -168,7 +168,8 @@ __device__ __forceinline__ void chunk_bwd12k_body(const ScanArgs& a, const unsig
     const int tid = tid_, lane = tid & 63;
     const SplitConst spc = split_const();
     const int hwid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int part = SPLIT ? (int)(slot & 1) : 0, bh = SPLIT ? (int)(slot >> 1) : (int)slot;
+    const int part = SPLIT ? (int)(slot & 1) : 0;
+    const int bh = SPLIT ? (int)(slot >> 1) : (CLK ? (int)xcd_row_of_slot(slot, (unsigned)(a.B * a.H)) : (int)slot);   // (CLK: the plain kernel)
     const int wid = SPLIT ? (hwid < 4 ? hwid + 4 * part : hwid + 4) : hwid;
     const bool rowrole = ROLE ? ROLE == 1 : wid < 4, producer = ROLE ? ROLE == 3 : wid >= 8;
     const int wv = wid & 3;                                              // tile owned by a row / column wave
