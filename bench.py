@@ -473,6 +473,7 @@ def main():
     if world > 1 or all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()                          # (the communicator exists before the pre-warm: its first collective is not a cold start)
 
     from rwkv_lm_ext_amd import wkv6_op
 
@@ -481,7 +482,7 @@ def main():
     fwd, bwd, tokens, B, T, H, name = build_workload(args.workload, dev, seed=rank)
     C = H * 64
 
-    from rwkv_lm_ext_amd.dp import timed_steps
+    from rwkv_lm_ext_amd.dp import hold_until_all_ranks_ready, timed_steps
     # Everything the timed region needs exists BEFORE the pre-warm: events, the clock ring, the first use of every kernel (module load,
     # LDS attributes, the library's device self-test).  Between the pre-warm, the W warm-up steps and the first timed step the host does
     # nothing but launch: an idle gap of a few milliseconds re-arms the boost -> clamp -> recover transient of the power manager
@@ -511,6 +512,8 @@ def main():
     # workgroup and launch, inside the timed region like everything else) into a ring of the last `ring` launches per kernel
     with wkv6_op.ClockProbe(dev, n_slots=64, n_launches=ring) as probe:
         prewarm = prewarm_until_steady(fwd, bwd)
+        # N > 1: the ranks converge at different moments; a ready rank keeps launching until all are (no idle GPU at the fence's barrier)
+        prewarm["prewarm_hold_iters"] = hold_until_all_ranks_ready(lambda: (fwd(), bwd()), dist, dev)
         # under a profiler (tools/collect_profiles.sh) two empty marker kernels bracket the W warm-up + K timed steps in the dispatch list, so
         # that tools/aggregate_profiles.py can average the TIMED launches only (the last K of each kernel between the markers); both are
         # launches, not waits, and both lie outside the timed region

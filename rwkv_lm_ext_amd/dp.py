@@ -79,3 +79,24 @@ def timed_steps(step: Callable[[], None], steps: int, warmup: int, device_sync: 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def hold_until_all_ranks_ready(step: Callable[[], None], dist=None, device: Optional[torch.device] = None, max_s: float = 5.0) -> int:
+    """Multi-rank pre-warm hand-over: each rank's own pre-warm ends when ITS step times have converged, which is not the same moment on
+    every rank -- and a rank that then sat idle at the timing fence's barrier would enter its timed steps on a cold GPU (an idle gap of
+    >= 1 ms re-arms the power manager's boost -> clamp -> recover transient, worth up to -18 % on the next 20 steps: bench.py,
+    profiles/r06_dvfs_transient.txt).  So a rank that is ready posts an asynchronous all-reduce and KEEPS LAUNCHING `step`, one per poll,
+    until the collective completes, i.e. until every rank is ready: all ranks leave within one step of each other and reach the fence's
+    barrier together.  Returns the number of extra steps launched (0 without a process group)."""
+    if dist is None or not dist.is_initialized():
+        return 0
+    flag = torch.ones(1, dtype=torch.float32, device=device or "cpu")
+    work = dist.all_reduce(flag, async_op=True)
+    extra, t0 = 0, time.perf_counter()
+    while not work.is_completed():
+        step()
+        extra += 1
+        if time.perf_counter() - t0 > max_s:       # a peer is far behind (or gone): stop feeding, wait for it
+            break
+    work.wait()
+    return extra

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from rwkv_lm_ext_amd.dp import BucketBatchSampler, shard_rows, timed_steps
+from rwkv_lm_ext_amd.dp import BucketBatchSampler, hold_until_all_ranks_ready, shard_rows, timed_steps
 
 
 def test_sampler_deals_disjoint_contiguous_slices():
@@ -78,3 +78,37 @@ def test_two_rank_gloo_timing_and_sharding():
     assert n0 == n1 == 4                                           # 1 warm-up + 3 timed steps each
     assert el0 == el1 and el0 >= 3 * 0.04 * 0.9                    # both report the slowest rank's time
     assert tot0 == tot1 == 28.0
+
+
+def _hold_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    time.sleep(0.4 * rank)                     # rank 1's "pre-warm" converges 0.4 s later than rank 0's
+    t_ready = time.perf_counter()
+    extra = hold_until_all_ranks_ready(lambda: time.sleep(0.005), dist)
+    held = time.perf_counter() - t_ready
+    t_left = time.time()
+    dist.barrier()
+    q.put((rank, extra, held, t_left))
+    dist.destroy_process_group()
+
+
+def test_ready_ranks_keep_launching_until_every_rank_is_ready():
+    """bench.py's multi-rank pre-warm hand-over (dp.hold_until_all_ranks_ready): the early rank does not idle -- it keeps stepping for as
+    long as the late rank needs -- and both leave within a few steps of each other."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hold_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, extra0, held0, left0), (_, extra1, held1, left1) = res
+    assert extra0 >= 30 and held0 >= 0.3           # rank 0 stepped through rank 1's remaining 0.4 s (5 ms steps)
+    assert extra1 <= 10 and held1 < 0.2            # rank 1 was the last to arrive: released almost at once
+    assert abs(left0 - left1) < 0.1                # and they left together
+    assert hold_until_all_ranks_ready(lambda: None, None) == 0
