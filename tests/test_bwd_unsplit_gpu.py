@@ -264,3 +264,25 @@ def test_ragged_rows_with_the_reference_decay_kind_share_one_fused_launch(ops, t
             if n != "gu":
                 for b in range(B):
                     assert np.all(c[b, int(lens[b]):] == 0), (n, b)
+
+
+@pytest.mark.parametrize("ew", [False, True], ids=["raw_w", "fp32_ew"])
+def test_chained_persistent_launches_equal_the_two_launch_halves_bit_for_bit(ops, two_level, monkeypatch, ew):
+    """Round 6 chained the calls of the persistent wkv6_bi backward (a call's producers, column and row waves prepare the call that follows;
+    the stage -> LDS slot maps rotate across the call boundary) and fused the fp32-ew kind: every wave still does the arithmetic of the plain
+    two-launch kernels (WKV6_BI_FUSED=0), so forward and backward must agree BIT FOR BIT -- on rows of every chaining case: fewer than two
+    stages (not chained, nor chained into), exactly two, odd and even stage counts, several rows per workgroup slot."""
+    B, T, H = 12, 330, 32                                             # 384 rows on 256 slots: a second row behind half of the slots
+    lens = torch.tensor([330, 0, 1, 32, 33, 64, 65, 96, 97, 128, 200, 313], dtype=torch.int32, device="cuda")
+    d = [dev(t, BF) for t in rand_inputs(9393, B, T, H, "stress")]
+    if ew:
+        d[3] = (-torch.exp(d[3].float())).contiguous()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WKV6_BI_FUSED", mode)
+        ws = ops.bi_new_workspace(B, T, H * 64, H, "cuda")
+        y = ops.bi_forward_ex(None, *d[:5], H, ws=ws, lens=lens, w_is_ew=ew)
+        g = ops.bi_backward_ex(None, *d, H, ws=ws, lens=lens, w_is_ew=ew)
+        outs[mode] = [host(y)] + [host(t) for t in g]
+    for n, a_, b_ in zip(("y", "gr", "gk", "gv", "gw", "gu"), outs["1"], outs["0"]):
+        assert np.array_equal(a_, b_), (n, float(np.abs(a_ - b_).max()))
