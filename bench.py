@@ -579,6 +579,11 @@ def main():
                        "fwd_kernel_ms_steps": fwd_kus or None, "bwd_kernel_ms_steps": bwd_kus or None,
                        "first_last_step_ratio": round((fwd_kus[-1] + bwd_kus[-1]) / (fwd_kus[0] + bwd_kus[0]), 4) if fwd_kus and bwd_kus
                        else round((fwd_steps[-1] + bwd_steps[-1]) / (fwd_steps[0] + bwd_steps[0]), 4),
+                       # drift indicator that single-launch jitter (+-3 % in the steadiest state: profiles/r06_dvfs_transient.txt, table A) does
+                       # not dominate: mean of the last quarter of the timed steps / mean of the first quarter (kernels alone)
+                       "tail_head_ratio": (lambda ks: round((sum(ks[-max(1, len(ks) // 4):]) / max(1, len(ks) // 4)) /
+                                                            (sum(ks[:max(1, len(ks) // 4)]) / max(1, len(ks) // 4)), 4))(
+                           [a + b for a, b in zip(fwd_kus, bwd_kus)] if fwd_kus and bwd_kus else [a + b for a, b in zip(fwd_steps, bwd_steps)]),
                        "step_spread": round((max(a + b for a, b in zip(fwd_steps, bwd_steps)) - min(a + b for a, b in zip(fwd_steps, bwd_steps)))
                                             / (fwd_ms + bwd_ms), 4),
                        # in-kernel shader clock of the timed launches of each kernel: d(s_memtime) / d(s_memrealtime) x 100 MHz, median
