@@ -5,6 +5,8 @@
 #   bash tools/build_exp_variant.sh noloads      # backward: ... and the r, k, v, w, gy loads too (zero-sized resources return 0): only checkpoints move
 #   bash tools/build_exp_variant.sh fwd_nostore  # forward: y and checkpoint stores dropped
 #   bash tools/build_exp_variant.sh fwd_noloads  # forward: ... and the r, k, v, w loads too: no memory traffic at all
+#   bash tools/build_exp_variant.sh halfck       # both: HALF of every checkpoint's bytes stored by the forward / fetched by the backward (wrong results): what a
+#                                                #   checkpoint of 2 B per token-channel (a compressed format, a 128-token spacing) could buy at most
 #   bash tools/build_exp_variant.sh full         # both: the producers' past-the-end selects compiled out (right only where every stage / group is full:
 #                                                #   T a multiple of 64 and no per-row lengths -- config 2): what a tail-free instantiation would buy
 set -e
@@ -43,6 +45,23 @@ if name == "fwd_noloads":
     assert "ntok > 0 ? span * 2 + 128 : 0" in s and "ntok > 0 ? span * 4 + 256 : 0" in s
     s = s.replace("ntok > 0 ? span * 2 + 128 : 0", "0").replace("ntok > 0 ? span * 4 + 256 : 0", "0")
 open(p, "w").write(s)
+PY
+  ;;
+  halfck) python3 - "$src/rwkv_lm_ext_amd/csrc" <<'PY'
+import sys
+d = sys.argv[1]
+p = d + "/wkv6_chunk.hip"; s = open(p).read()
+old = """                    for (int wb = 0; wb < 4; ++wb)
+                        __builtin_amdgcn_raw_buffer_store_b128(ckd[wb], rs_ck, ck_off + wb * 4096, 0, 2 /* slc: streaming */);"""
+assert old in s
+open(p, "w").write(s.replace(old, old.replace("wb < 4", "wb < 2")))
+p = d + "/wkv6_chunk_bwd12k.hip"; s = open(p).read()
+old = """            for (int jt = 0; jt < 4; ++jt) {
+                const float4 t = buf_load16f(rs_ck, off + jt * 1024u);
+                CK[jt] = f4v{t.x, t.y, t.z, t.w};
+            }"""
+assert old in s
+open(p, "w").write(s.replace(old, old.replace("jt < 4", "jt < 2") + "\n            CK[2] = CK[0]; CK[3] = CK[1];"))
 PY
   ;;
   full) python3 - "$src/rwkv_lm_ext_amd/csrc" <<'PY'
