@@ -223,3 +223,21 @@ def test_oracle_matches_the_medium_reference_fixtures(oracle):
     ob = oracle.bi_backward(mask, *a, g["gy"])
     for n in ("gr", "gk", "gv", "gw", "gu"):
         assert max_norm_err(ob[n], g[n]) <= 2e-5, n
+
+
+def test_clock_ring_host_bookkeeping():
+    """wkv6_set_clock_ring / wkv6_clock_ring_counts (include/wkv6_amd.h, measurement aids): setting the ring resets the per-kernel launch
+    counts, nothing is launched or dereferenced on the host, NULL switches the probe off; the python wrapper's no-op contract for A/B
+    libraries that predate the symbols rests on _lib.has_symbol."""
+    import ctypes
+    from rwkv_lm_ext_amd import _lib
+    lib = _lib.load()
+    assert all(_lib.has_symbol(s) for s in _lib.MEASUREMENT_AIDS)
+    f, b = ctypes.c_long(-1), ctypes.c_long(-1)
+    lib.wkv6_set_clock_ring(ctypes.c_void_p(0x1000), 64, 128)      # (a device address as far as the library knows: only handed to kernels)
+    lib.wkv6_clock_ring_counts(ctypes.byref(f), ctypes.byref(b))
+    assert (f.value, b.value) == (0, 0)
+    lib.wkv6_set_clock_ring(None, 0, 0)
+    lib.wkv6_set_clock_buffer(None, 0)
+    lib.wkv6_clock_ring_counts(ctypes.byref(f), None)
+    assert f.value == 0
