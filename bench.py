@@ -487,7 +487,9 @@ def main():
     # LDS attributes, the library's device self-test).  Between the pre-warm, the W warm-up steps and the first timed step the host does
     # nothing but launch: an idle gap of a few milliseconds re-arms the boost -> clamp -> recover transient of the power manager
     # (profiles/r06_dvfs_transient.txt), which is worth +-20 % on a 14 ms window.
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    # two events per timed step, not three: a step's closing event IS the next step's opening one (an event record costs the stream ~2 us --
+    # tools/event_overhead.py: 0 / 1 / 2 / 3 records per step = 0.5557 / 0.5569 / 0.5592 / 0.5617 ms per step -- and is instrumentation, not work)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps + 1)]
     counter = {"i": -args.warmup}
     launches_per_pass = 8 if args.workload == "infctx" else 1
     ring = launches_per_pass * (args.steps + args.warmup + 8)
@@ -495,14 +497,14 @@ def main():
     def step():                       # HIP events on the launch stream bracket fwd and bwd of every timed step
         i = counter["i"]
         counter["i"] += 1
-        if i >= 0:
-            ev[i][0].record()
+        if i == 0:
+            ev[0][0].record()
         fwd()
         if i >= 0:
             ev[i][1].record()
         bwd()
         if i >= 0:
-            ev[i][2].record()
+            ev[i + 1][0].record()         # closes step i, opens step i + 1
 
     fwd()
     bwd()
@@ -510,6 +512,11 @@ def main():
     # in-run shader clock and duration of every launch of the warm-up and timed steps: wave 0 of the first 64 workgroups of the plain
     # chunked kernels stamps {s_memtime, s_memrealtime} at its start and end (four scalar instructions and two 8-byte stores per
     # workgroup and launch, inside the timed region like everything else) into a ring of the last `ring` launches per kernel
+    # no garbage-collector pause between here and the end of the timed region: a generation-2 collection over the interpreter's ~10^6 objects
+    # takes tens of milliseconds, and a host that stops launching for >= 1 ms re-arms the clock transient the pre-warm has just outlasted
+    import gc
+    gc.collect()
+    gc.disable()
     with wkv6_op.ClockProbe(dev, n_slots=64, n_launches=ring) as probe:
         prewarm = prewarm_until_steady(fwd, bwd)
         # N > 1: the ranks converge at different moments; a ready rank keeps launching until all are (no idle GPU at the fence's barrier)
@@ -524,8 +531,9 @@ def main():
         if marked:
             wkv6_op.pass_marker()
         clocks = probe.read()
-    fwd_steps = [e[0].elapsed_time(e[1]) for e in ev]
-    bwd_steps = [e[1].elapsed_time(e[2]) for e in ev]
+    gc.enable()
+    fwd_steps = [ev[i][0].elapsed_time(ev[i][1]) for i in range(args.steps)]
+    bwd_steps = [ev[i][1].elapsed_time(ev[i + 1][0]) for i in range(args.steps)]
     fwd_ms = sum(fwd_steps) / args.steps
     bwd_ms = sum(bwd_steps) / args.steps
 
