@@ -114,3 +114,54 @@ def test_no_integer_multiply_in_the_benched_kernels_loops():
                     elif in_loop and re.match(r"\s+v_(mul_lo_u32|mul_hi_u32|mad_u64_u32)", line):
                         raise AssertionError(f"{name}: integer multiply inside a loop: {line.strip()}")
             assert seen == len(names), (src, seen)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_chained_wkv6_bi_backward_keeps_full_drains_out_of_its_stage_loops():
+    """Round 6: the persistent wkv6_bi backward chains its calls -- the column waves' requests for the call that follows are issued
+    unconditionally from a SELECTED row (as branches they made the loaded registers merges, which hipcc resolved with `s_waitcnt vmcnt(0)`
+    inside the stage loop: every stage then waited for its own fresh requests and the previous stage's store acknowledgements, the round-4
+    stall).  From the ISA of chunk_bwd12k_bi_kernel (both decay kinds): the stage loops (depth 2; the row walk is depth 1) of the row waves
+    of both halves and of the column waves of the first half wait with counted vmcnt only.  (The second half's column loop adds the first
+    half's partial to its result right behind the load: its vmcnt(0) predates the chaining.)"""
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-w", "-S", "--cuda-device-only"]
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.check_call(["hipcc"] + flags + ["-o", out, os.path.join(root, "rwkv_lm_ext_amd", "csrc", "wkv6_chunk_bwd12k.hip")])
+        asm = open(out).read()
+    seen = 0
+    for fn in re.split(r"\n(?=_Z[\w]+:)", asm):
+        if "chunk_bwd12k_bi_kernel" not in fn.split(":", 1)[0]:
+            continue
+        seen += 1
+        loops, cur = {}, None
+        for line in fn.split("\n"):
+            m = re.match(r"^\.L(BB\d+_\d+):\s*(;.*)?$", line)
+            if m:
+                c = m.group(2) or ""
+                h = re.search(r"Header=(BB\d+_\d+) Depth=2", c)
+                cur = m.group(1) if "Loop Header: Depth=2" in c else (h.group(1) if h else None)
+                continue
+            if cur is None:
+                continue
+            d = loops.setdefault(cur, {"stores": 0, "mfma": 0, "waits": []})
+            op = line.strip().split(" ")[0] if line.strip() else ""
+            if op.startswith("buffer_store"):
+                d["stores"] += 1
+            elif op.startswith("v_mfma"):
+                d["mfma"] += 1
+            elif op == "s_waitcnt":
+                w = re.search(r"vmcnt\((\d+)\)", line)
+                if w:
+                    d["waits"].append(int(w.group(1)))
+        consuming = [v for v in loops.values() if v["stores"] > 0 and v["mfma"] > 0]
+        assert len(consuming) == 4, {k: (v["stores"], v["mfma"]) for k, v in loops.items()}     # row + column waves of both halves
+        second_half_column = min(consuming, key=lambda v: v["stores"])                           # one merged gv store per stage
+        for v in consuming:
+            if v is not second_half_column:
+                assert 0 not in v["waits"], v
+    assert seen == 2
